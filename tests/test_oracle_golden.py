@@ -1,0 +1,108 @@
+"""Pin the CPU oracle (oracle/corr_oracle.py) to vectors captured from the reference's own
+CorrBlock1D / PytorchAlternateCorrBlock1D (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import corr_oracle as O
+from conftest import GOLDEN_CASES
+
+KINDS = ["smooth", "random", "edge"]
+TOL = 1e-5          # max|a-b| / max|ref|, the fp32 bar of BASELINE.json
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_volume_and_pyramid(golden, case):
+    g = golden(case)
+    L = int(g["L"])
+    pyr = O.pool_pyramid(O.corr_volume(g["f1"], g["f2"]), L)
+    for i in range(L):
+        assert pyr[i].shape == g[f"level{i}"].shape
+        assert O.rel_to_max(pyr[i], g[f"level{i}"]) < 2e-6
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+@pytest.mark.parametrize("kind", KINDS)
+def test_lookup_gridsample_matches_reg(golden, case, kind):
+    g = golden(case)
+    L, r = int(g["L"]), int(g["r"])
+    pyr = [g[f"level{i}"] for i in range(L)]
+    out = O.lookup_gridsample(pyr, g[f"coords_{kind}"], r)
+    assert out.shape == g[f"lookup_{kind}"].shape
+    assert O.rel_to_max(out, g[f"lookup_{kind}"]) < 2e-6
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+@pytest.mark.parametrize("kind", KINDS)
+def test_lookup_exact_close_to_reg(golden, case, kind):
+    """The floor+lerp form (sampler_kernel.cu, the reference's own native lookup) differs from
+    the reg path only through the fp32 round trip of the tap coordinate in bilinear_sampler:
+    a few ulp(x) times the local slope, i.e. up to ~1e-5..1e-4 of max at widths of hundreds.
+    That is why the HIP lookup has a grid_sample-compatible coordinate mode for fp32 parity."""
+    g = golden(case)
+    L, r = int(g["L"]), int(g["r"])
+    pyr = [g[f"level{i}"] for i in range(L)]
+    out = O.lookup_exact(pyr, g[f"coords_{kind}"], r)
+    assert O.rel_to_max(out, g[f"lookup_{kind}"]) < 1e-4
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_far_out_of_range_is_zero(golden, case):
+    g = golden(case)
+    L, r = int(g["L"]), int(g["r"])
+    c = g["coords_edge"]
+    far = np.abs(c[:, 0]) >= 1e3
+    assert far.any()
+    ref = g["lookup_edge"].transpose(0, 2, 3, 1)[far]
+    assert np.all(ref == 0)
+    out = O.lookup_exact([g[f"level{i}"] for i in range(L)], c, r).transpose(0, 2, 3, 1)[far]
+    assert np.all(out == 0)
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_backward_single_and_multi(golden, case):
+    g = golden(case)
+    L, r = int(g["L"]), int(g["r"])
+    widths = [g[f"level{i}"].shape[-1] for i in range(L)]
+    acc = None
+    for n, kind in enumerate(KINDS):
+        lg = O.lookup_bwd(g[f"coords_{kind}"], g[f"gout_{kind}"], widths, r, O.GRIDSAMPLE)
+        acc = lg if acc is None else [a + b for a, b in zip(acc, lg)]
+        if n == 0:
+            df1, df2 = O.corr_volume_bwd(O.pool_pyramid_bwd(acc), g["f1"], g["f2"])
+            assert O.rel_to_max(df1, g["df1_single"]) < TOL
+            assert O.rel_to_max(df2, g["df2_single"]) < TOL
+    df1, df2 = O.corr_volume_bwd(O.pool_pyramid_bwd(acc), g["f1"], g["f2"])
+    assert O.rel_to_max(df1, g["df1_multi"]) < TOL
+    assert O.rel_to_max(df2, g["df2_multi"]) < TOL
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+@pytest.mark.parametrize("kind", KINDS)
+def test_alt_matches_reference_alt_and_reg(golden, case, kind):
+    g = golden(case)
+    L, r = int(g["L"]), int(g["r"])
+    out = O.alt_lookup(g["f1"], g["f2"], g[f"coords_{kind}"], L, r, O.GRIDSAMPLE)
+    # the bar is the reg path; the reference's own alt also round-trips y, so it is looser
+    assert O.rel_to_max(out, g[f"lookup_{kind}"]) < TOL
+    assert O.rel_to_max(out, g[f"alt_{kind}"]) < 5e-5
+    out = O.alt_lookup(g["f1"], g["f2"], g[f"coords_{kind}"], L, r, O.EXACT)
+    assert O.rel_to_max(out, g[f"lookup_{kind}"]) < 1e-4
+
+
+def test_pool_rounding_hook():
+    v = np.linspace(-3, 3, 4 * 5 * 6 * 16, dtype=np.float32).reshape(4, 5, 6, 16)
+    p16 = O.pool_pyramid(v, 3, round_to=np.float16)
+    assert all(np.array_equal(x, x.astype(np.float16).astype(np.float32)) for x in p16)
+    pb = O.pool_pyramid(v, 3, round_to=O.round_bf16)
+    assert all(np.array_equal(x, O.round_bf16(x)) for x in pb)
+
+
+def test_reg_torch_port_matches_golden(golden):
+    """The torch-op port used as the CPU baseline reproduces the reference's outputs."""
+    import torch
+    from oracle.reg_torch import RegCorrCPU
+    g = golden("tiny_b2_d32_h3_w24")
+    blk = RegCorrCPU(torch.from_numpy(g["f1"]), torch.from_numpy(g["f2"]), 4, 4)
+    for kind in KINDS:
+        out = blk(torch.from_numpy(g[f"coords_{kind}"])).numpy()
+        assert O.rel_to_max(out, g[f"lookup_{kind}"]) < 2e-6
