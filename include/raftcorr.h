@@ -1,0 +1,168 @@
+/*
+ * raftcorr.h -- C-ABI of libraftcorr_hip.so: the MI355X (gfx950) correlation hot path of
+ * RAFT-Stereo (volume build + pooled pyramid, per-iteration lookup fwd/bwd, build adjoint,
+ * on-the-fly "alt" lookup).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller; the library never allocates,
+ *     frees or keeps a pointer past the call, and holds no global state besides a
+ *     thread-local error string;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream);
+ *   - every function returns 0 on success, a negative RC_E* code for argument errors, or a
+ *     positive hipError_t for launch errors; rc_last_error_string() explains the last
+ *     failure of the calling thread;
+ *   - the functions are re-entrant and may be called concurrently from several host
+ *     threads (nn.DataParallel-style) on different devices/streams; the caller makes the
+ *     right device current before the call.
+ *
+ * Reference interfaces replaced (paths inside the upstream RAFT-Stereo tree):
+ *   rc_build_pyramid   core/corr.py:111-125 + :148-156   CorrBlock1D.__init__ / .corr
+ *                      core/corr.py:32-42  + :53-61      CorrBlockFast1D.__init__ / .corr
+ *   rc_lookup_fwd      core/corr.py:127-146 (reg, grid_sample coordinates) and
+ *                      core/corr.py:44-51 -> sampler/sampler.cpp:24-32 ->
+ *                      sampler/sampler_kernel.cu:19-60,107-136 (reg_cuda), all levels at once
+ *   rc_lookup_bwd      core/corr.py:24-29 -> sampler/sampler.cpp:34-45 ->
+ *                      sampler/sampler_kernel.cu:63-105,138-166
+ *   rc_build_bwd       autograd of core/corr.py:119-125 (avg_pool2d chain) and :154-156
+ *   rc_sampler_fwd/bwd sampler/sampler.cpp:48-51 `corr_sampler.forward/backward` on the
+ *                      caller's own row-major [B,H,W1,W2] single-level volume
+ *   rc_alt_prepare,
+ *   rc_alt_fwd         core/corr.py:64-107 PytorchAlternateCorrBlock1D (volume never built)
+ */
+#ifndef RAFTCORR_H
+#define RAFTCORR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RC_VERSION 100          /* 0.1.0 */
+#define RC_MAX_LEVELS 4
+#define RC_MAX_RADIUS 8
+
+/* element types of feature maps / volumes */
+enum { RC_F32 = 0, RC_F16 = 1, RC_BF16 = 2 };
+
+/* how a tap's sampling position is derived from coords (see oracle/corr_oracle.py tap_coords) */
+enum {
+  RC_COORD_EXACT = 0,      /* floor + lerp of sampler_kernel.cu:42-57 (reg_cuda semantics)   */
+  RC_COORD_GRIDSAMPLE = 1  /* reg semantics: 2x/(W-1)-1 then grid_sample(align_corners=True)  */
+};
+
+/* error codes (negative); positive return values are hipError_t */
+enum {
+  RC_OK = 0,
+  RC_EINVAL = -1,       /* bad shape / null pointer / misaligned pointer */
+  RC_EUNSUPPORTED = -2, /* dtype / radius / level count outside the compiled range */
+  RC_ENODEVICE = -3
+};
+
+/*
+ * Private layout of the correlation pyramid ("skewed", disparity-major):
+ * level i holds B*H row-blocks of width[i] skew rows of `pitch` elements;
+ * element (b,h,w1,w2) of level i lives at
+ *     offset[i] + ((b*H + h) * width[i] + s) * pitch + w1,   s = ((w1 >> i) - w2) mod width[i]
+ * so that, for a fixed tap, neighbouring pixels of one image row with similar disparity read
+ * consecutive addresses.  Nothing outside this library and its Python wrapper may index it.
+ */
+typedef struct rc_layout {
+  int64_t B, H, W1, W2;
+  int32_t L;                        /* levels stored (= levels ever read, corr.py:133-134) */
+  int32_t pitch;                    /* W1 rounded up to a multiple of 64 elements */
+  int32_t width[RC_MAX_LEVELS];     /* W2 >> i */
+  int64_t offset[RC_MAX_LEVELS];    /* element offset of level i */
+  int64_t total;                    /* elements in the whole pyramid */
+} rc_layout;
+
+int rc_version(void);
+const char* rc_last_error_string(void);
+
+/* Fills *out; RC_EINVAL if W2 >> (L-1) < 1 or any size is non-positive. */
+int rc_pyramid_layout(int64_t B, int64_t H, int64_t W1, int64_t W2, int L, rc_layout* out);
+
+/*
+ * Build all levels of the pyramid: C = f1^T f2 / sqrt(D) per image row, then the pairwise
+ * mean chain, written in the private layout.  f1: [B,D,H,W1], f2: [B,D,H,W2] contiguous
+ * NCHW of `in_dtype`; vol: lay->total elements of `vol_dtype`.
+ * Arithmetic: RC_F32 inputs use the exact-f32 MFMA (v_mfma_f32_16x16x4_f32), RC_F16/RC_BF16
+ * inputs the 16x16x32 f16/bf16 MFMA with f32 accumulation; levels >= 1 are means of the
+ * already-rounded lower level (what avg_pool2d on a 16-bit volume does, corr.py:42).
+ * Supported: (in,vol) = (F32,F32), (F16,F16), (BF16,BF16), (F16|BF16, F32).
+ */
+int rc_build_pyramid(const void* f1, const void* f2, void* vol, const rc_layout* lay,
+                     int64_t D, int in_dtype, int vol_dtype, void* stream);
+/* Diagnostic twin (no counterpart in the reference): same contract, but always runs the
+ * one-thread-per-element kernels that rc_build_pyramid only falls back to for D > 256.
+ * Used by the GPU tests as an on-device cross-check of the MFMA kernel. */
+int rc_build_pyramid_naive(const void* f1, const void* f2, void* vol, const rc_layout* lay,
+                           int64_t D, int in_dtype, int vol_dtype, void* stream);
+
+/*
+ * Lookup, all levels in one launch.
+ * coords: float [B, coords_channels, H, W1] (channel 0 = x; other channels ignored);
+ * out:    float [B, L*(2r+1), H, W1], channel = level*(2r+1) + tap  (corr.py:145-146).
+ */
+int rc_lookup_fwd(const void* vol, const rc_layout* lay, int vol_dtype, const float* coords,
+                  int coords_channels, float* out, int radius, int coord_mode, void* stream);
+
+/*
+ * Adjoint of rc_lookup_fwd w.r.t. the pyramid.  grad_vol is a float pyramid in the same
+ * layout that is ACCUMULATED into (+=): zero it once per forward pass, then call this once
+ * per lookup.  Calls on one stream are ordered; no atomics are used (a pixel owns its column).
+ */
+int rc_lookup_bwd(const float* coords, int coords_channels, const float* grad_out,
+                  float* grad_vol, const rc_layout* lay, int radius, int coord_mode,
+                  void* stream);
+
+/*
+ * Adjoint of rc_build_pyramid: folds the level gradients into level 0 and contracts with the
+ * feature maps: df1[b,d,h,w1] = sum_w2 dC f2 / sqrt(D), df2[b,d,h,w2] = sum_w1 dC f1 / sqrt(D).
+ * df1/df2 have the dtype and shape of f1/f2.  `work` is scratch of rc_build_bwd_work_bytes().
+ */
+int64_t rc_build_bwd_work_bytes(const rc_layout* lay, int in_dtype);
+int rc_build_bwd(const float* grad_vol, const rc_layout* lay, const void* f1, const void* f2,
+                 void* df1, void* df2, int64_t D, int in_dtype, void* work, void* stream);
+
+/*
+ * Drop-in for the reference's `corr_sampler` extension (sampler/sampler.cpp:48-51): one
+ * level, the caller's row-major volume [B,H,W1,W2] of `dtype`, coords [B,coords_channels,H,W1]
+ * float, corr / corr_grad [B,2r+1,H,W1] of `dtype`.  rc_sampler_bwd OVERWRITES volume_grad
+ * (the reference returns a fresh zeros_like, sampler_kernel.cu:148).
+ */
+int rc_sampler_fwd(const void* volume, const float* coords, int coords_channels, void* corr,
+                   int64_t B, int64_t H, int64_t W1, int64_t W2, int radius, int dtype,
+                   void* stream);
+int rc_sampler_bwd(const float* coords, int coords_channels, const void* corr_grad,
+                   void* volume_grad, int64_t B, int64_t H, int64_t W1, int64_t W2, int radius,
+                   int dtype, void* stream);
+
+/*
+ * On-the-fly ("alt") correlation.  rc_alt_prepare converts the feature maps once per image
+ * pair into channel-last working copies: f1t [B,H,W1,Dp] and the pooled f2 pyramid
+ * f2t level i [B,H,W2>>i,Dp] (Dp = D rounded up to 32, zero padded), both of `in_dtype`.
+ * rc_alt_fwd then computes the same [B, L*(2r+1), H, W1] float output as rc_lookup_fwd from
+ * banded MFMA products, without ever materialising the volume.
+ */
+typedef struct rc_alt_layout {
+  int64_t B, H, W1, W2, D, Dp;
+  int32_t L;
+  int32_t width[RC_MAX_LEVELS];
+  int64_t f1_elems;                 /* elements of f1t */
+  int64_t f2_offset[RC_MAX_LEVELS]; /* element offset of level i inside f2t */
+  int64_t f2_elems;                 /* elements of the whole f2t pyramid */
+} rc_alt_layout;
+
+int rc_alt_layout_init(int64_t B, int64_t D, int64_t H, int64_t W1, int64_t W2, int L,
+                       rc_alt_layout* out);
+int rc_alt_prepare(const void* f1, const void* f2, void* f1t, void* f2t,
+                   const rc_alt_layout* lay, int in_dtype, void* stream);
+int rc_alt_fwd(const void* f1t, const void* f2t, const rc_alt_layout* lay, int in_dtype,
+               const float* coords, int coords_channels, float* out, int radius,
+               int coord_mode, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAFTCORR_H */

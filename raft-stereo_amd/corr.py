@@ -1,0 +1,240 @@
+"""Correlation blocks with the reference's interface, backed by libraftcorr_hip.so.
+
+    block = CorrBlock1DHip(fmap1, fmap2, num_levels=4, radius=4)     # core/corr.py:111
+    corr  = block(coords)            # [B, num_levels*(2*radius+1), H, W] fp32   core/corr.py:127
+
+CorrBlock1DHip    -> `reg_hip`  (replaces CorrBlock1D, core/corr.py:110-156, and
+                                  CorrBlockFast1D + CorrSampler, core/corr.py:17-61)
+AltCorrBlock1DHip -> `alt_hip`  (replaces PytorchAlternateCorrBlock1D, core/corr.py:64-107)
+CorrSamplerHip mirrors the autograd wrapper of core/corr.py:17-29 on top of the
+`corr_sampler` twin (row-major single-level volumes) for callers of that lower-level interface.
+
+Torch only owns memory, streams and the autograd graph here; all arithmetic is in the HIP
+library.  There is no CPU or eager fallback: tensors must live on a GPU.
+"""
+import torch
+
+from raft_stereo_amd import _lib, sampler
+from raft_stereo_amd._lib import lib, check, Layout, AltLayout
+
+_DT = {torch.float32: _lib.RC_F32, torch.float16: _lib.RC_F16, torch.bfloat16: _lib.RC_BF16}
+COORD_MODES = {"exact": _lib.RC_COORD_EXACT, "gridsample": _lib.RC_COORD_GRIDSAMPLE}
+
+
+def _stream(dev):
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _check_fmaps(fmap1, fmap2, num_levels, radius):
+    if fmap1.dim() != 4 or fmap2.dim() != 4:
+        raise ValueError("fmap1/fmap2 must be [B, D, H, W]")
+    if not (fmap1.is_cuda and fmap2.is_cuda):
+        raise RuntimeError("raft_stereo_amd correlation blocks need GPU tensors (there is no CPU path)")
+    if fmap1.device != fmap2.device:
+        raise RuntimeError("fmap1 and fmap2 live on different devices")
+    if fmap1.dtype != fmap2.dtype or fmap1.dtype not in _DT:
+        raise TypeError(f"unsupported feature dtypes {fmap1.dtype}/{fmap2.dtype}")
+    B, D, H, W1 = fmap1.shape
+    B2, D2, H2, W2 = fmap2.shape
+    if (B, D, H) != (B2, D2, H2):
+        raise ValueError(f"fmap shapes disagree: {tuple(fmap1.shape)} vs {tuple(fmap2.shape)}")
+    if not (1 <= num_levels <= _lib.RC_MAX_LEVELS):
+        raise ValueError(f"num_levels must be in 1..{_lib.RC_MAX_LEVELS}")
+    if not (1 <= radius <= _lib.RC_MAX_RADIUS):
+        raise ValueError(f"radius must be in 1..{_lib.RC_MAX_RADIUS}")
+    if (W2 >> num_levels) < 1:
+        # the reference pools num_levels times (core/corr.py:123-125) and avg_pool2d raises
+        raise RuntimeError(f"Output size is too small: W2={W2} cannot be pooled {num_levels} times")
+    return B, D, H, W1, W2
+
+
+def _check_coords(coords, B, H, W1, device):
+    if coords.dim() != 4 or coords.shape[0] != B or coords.shape[2] != H or coords.shape[3] != W1 \
+            or coords.shape[1] < 1:
+        raise ValueError(f"coords must be [B={B}, >=1, H={H}, W={W1}], got {tuple(coords.shape)}")
+    if coords.device != device:
+        raise RuntimeError("coords live on a different device than the feature maps")
+    return coords.detach().float().contiguous()
+
+
+class _BuildFn(torch.autograd.Function):
+    """Builds the pyramid into block.volume and returns a 1-element token that ties every
+    lookup to the build in the autograd graph.  Its backward runs once, after all lookups'
+    backwards have accumulated into block.grad_volume."""
+
+    @staticmethod
+    def forward(ctx, fmap1, fmap2, block):
+        block._build(fmap1, fmap2)
+        ctx.block = block
+        ctx.save_for_backward(fmap1, fmap2)
+        return torch.zeros(1, dtype=torch.float32, device=fmap1.device)
+
+    @staticmethod
+    def backward(ctx, _grad_token):
+        fmap1, fmap2 = ctx.saved_tensors
+        block = ctx.block
+        gvol = block.grad_volume
+        block.grad_volume = None
+        if gvol is None:          # no lookup took part in the loss
+            return torch.zeros_like(fmap1), torch.zeros_like(fmap2), None
+        df1, df2 = torch.empty_like(fmap1), torch.empty_like(fmap2)
+        lay = block.layout
+        with torch.cuda.device(fmap1.device):
+            nbytes = lib.rc_build_bwd_work_bytes(lay, block.in_dtype)
+            if nbytes < 0:
+                raise _lib.RaftCorrError("rc_build_bwd_work_bytes rejected the layout")
+            work = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=fmap1.device)
+            check(lib.rc_build_bwd(gvol.data_ptr(), lay, fmap1.data_ptr(), fmap2.data_ptr(), df1.data_ptr(),
+                                   df2.data_ptr(), block.D, block.in_dtype, work.data_ptr(),
+                                   _stream(fmap1.device)), "rc_build_bwd")
+        return df1, df2, None
+
+
+class _LookupFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, token, coords, block):
+        ctx.block = block
+        ctx.save_for_backward(coords)
+        return block._lookup(coords)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (coords,) = ctx.saved_tensors
+        block = ctx.block
+        grad_out = grad_out.float().contiguous()        # core/corr.py:27
+        dev = coords.device
+        with torch.cuda.device(dev):
+            if block.grad_volume is None:
+                block.grad_volume = torch.zeros(block.layout.total, dtype=torch.float32, device=dev)
+            check(lib.rc_lookup_bwd(coords.data_ptr(), coords.shape[1], grad_out.data_ptr(),
+                                    block.grad_volume.data_ptr(), block.layout, block.radius,
+                                    block.coord_mode, _stream(dev)), "rc_lookup_bwd")
+        return torch.zeros(1, dtype=torch.float32, device=dev), None, None
+
+
+class CorrBlock1DHip:
+    """`reg_hip`: materialised all-pairs 1-D correlation pyramid + per-iteration lookup.
+
+    fp32 feature maps give an fp32 volume built with the exact-f32 MFMA and grid_sample-
+    compatible tap coordinates (the reg path, core/corr.py:110-156); fp16/bf16 feature maps (the
+    autocast case of reg_cuda, core/raft_stereo.py:96-97) give a 16-bit volume and the
+    floor+lerp coordinates of sampler_kernel.cu.  `coord_mode` overrides that choice.
+    Differentiable w.r.t. fmap1/fmap2 only (coords are detached, core/raft_stereo.py:109,
+    core/corr.py:29).
+    """
+
+    def __init__(self, fmap1, fmap2, num_levels=4, radius=4, coord_mode=None, volume_dtype=None):
+        B, D, H, W1, W2 = _check_fmaps(fmap1, fmap2, num_levels, radius)
+        self.num_levels, self.radius = num_levels, radius
+        self.B, self.D, self.H, self.W1, self.W2 = B, D, H, W1, W2
+        self.device = fmap1.device
+        self.in_dtype = _DT[fmap1.dtype]
+        self.volume_torch_dtype = volume_dtype or fmap1.dtype
+        if self.volume_torch_dtype not in (fmap1.dtype, torch.float32):
+            raise TypeError("volume_dtype must be the feature dtype or float32")
+        self.vol_dtype = _DT[self.volume_torch_dtype]
+        if coord_mode is None:
+            coord_mode = "gridsample" if fmap1.dtype == torch.float32 else "exact"
+        self.coord_mode = COORD_MODES[coord_mode]
+        self.layout = Layout()
+        check(lib.rc_pyramid_layout(B, H, W1, W2, num_levels, self.layout), "rc_pyramid_layout")
+        self.volume = None
+        self.grad_volume = None
+        fmap1, fmap2 = fmap1.contiguous(), fmap2.contiguous()
+        if torch.is_grad_enabled() and (fmap1.requires_grad or fmap2.requires_grad):
+            self._token = _BuildFn.apply(fmap1, fmap2, self)
+        else:
+            self._token = None
+            self._build(fmap1.detach(), fmap2.detach())
+
+    # -- raw calls into the library
+    def _build(self, fmap1, fmap2):
+        with torch.cuda.device(self.device):
+            self.volume = torch.empty(self.layout.total, dtype=self.volume_torch_dtype, device=self.device)
+            check(lib.rc_build_pyramid(fmap1.data_ptr(), fmap2.data_ptr(), self.volume.data_ptr(), self.layout,
+                                       self.D, self.in_dtype, self.vol_dtype, _stream(self.device)),
+                  "rc_build_pyramid")
+
+    def _lookup(self, coords):
+        nt = 2 * self.radius + 1
+        with torch.cuda.device(self.device):
+            out = torch.empty((self.B, self.num_levels * nt, self.H, self.W1), dtype=torch.float32,
+                              device=self.device)
+            check(lib.rc_lookup_fwd(self.volume.data_ptr(), self.layout, self.vol_dtype, coords.data_ptr(),
+                                    coords.shape[1], out.data_ptr(), self.radius, self.coord_mode,
+                                    _stream(self.device)), "rc_lookup_fwd")
+        return out
+
+    def __call__(self, coords):
+        coords = _check_coords(coords, self.B, self.H, self.W1, self.device)
+        if self._token is not None and torch.is_grad_enabled():
+            return _LookupFn.apply(self._token, coords, self)
+        return self._lookup(coords)
+
+    # -- test / debug helper: the pyramid in the reference's dense layout
+    def dense_level(self, i):
+        """Level i as a dense [B,H,W1,W2>>i] tensor (un-skews the private layout with torch
+        indexing; for tests only)."""
+        lay = self.layout
+        Wi, pitch = lay.width[i], lay.pitch
+        n = self.B * self.H * Wi * pitch
+        lvl = self.volume[lay.offset[i]:lay.offset[i] + n].view(self.B, self.H, Wi, pitch)
+        w1 = torch.arange(self.W1, device=self.device).view(-1, 1)
+        w2 = torch.arange(Wi, device=self.device).view(1, -1)
+        s = ((w1 >> i) - w2) % Wi
+        return lvl[:, :, s, w1.expand_as(s)]
+
+
+class AltCorrBlock1DHip:
+    """`alt_hip`: same outputs as CorrBlock1DHip without ever building the volume
+    (PytorchAlternateCorrBlock1D, core/corr.py:64-107).  Like the reg path it samples along x
+    only: coords channel 1 is the pixel's own row in RAFT-Stereo (core/raft_stereo.py:120)."""
+
+    def __init__(self, fmap1, fmap2, num_levels=4, radius=4, coord_mode=None):
+        B, D, H, W1, W2 = _check_fmaps(fmap1, fmap2, num_levels, radius)
+        if radius > 6:
+            raise ValueError("alt_hip supports radius <= 6")
+        self.num_levels, self.radius = num_levels, radius
+        self.B, self.D, self.H, self.W1, self.W2 = B, D, H, W1, W2
+        self.device = fmap1.device
+        self.in_dtype = _DT[fmap1.dtype]
+        if coord_mode is None:
+            coord_mode = "gridsample" if fmap1.dtype == torch.float32 else "exact"
+        self.coord_mode = COORD_MODES[coord_mode]
+        self.layout = AltLayout()
+        check(lib.rc_alt_layout_init(B, D, H, W1, W2, num_levels, self.layout), "rc_alt_layout_init")
+        fmap1, fmap2 = fmap1.detach().contiguous(), fmap2.detach().contiguous()
+        with torch.cuda.device(self.device):
+            self.f1t = torch.empty(self.layout.f1_elems, dtype=fmap1.dtype, device=self.device)
+            self.f2t = torch.empty(self.layout.f2_elems, dtype=fmap1.dtype, device=self.device)
+            check(lib.rc_alt_prepare(fmap1.data_ptr(), fmap2.data_ptr(), self.f1t.data_ptr(), self.f2t.data_ptr(),
+                                     self.layout, self.in_dtype, _stream(self.device)), "rc_alt_prepare")
+
+    def __call__(self, coords):
+        coords = _check_coords(coords, self.B, self.H, self.W1, self.device)
+        nt = 2 * self.radius + 1
+        with torch.cuda.device(self.device):
+            out = torch.empty((self.B, self.num_levels * nt, self.H, self.W1), dtype=torch.float32,
+                              device=self.device)
+            check(lib.rc_alt_fwd(self.f1t.data_ptr(), self.f2t.data_ptr(), self.layout, self.in_dtype,
+                                 coords.data_ptr(), coords.shape[1], out.data_ptr(), self.radius,
+                                 self.coord_mode, _stream(self.device)), "rc_alt_fwd")
+        return out
+
+
+class CorrSamplerHip(torch.autograd.Function):
+    """core/corr.py:17-29 on the HIP `corr_sampler` twin."""
+
+    @staticmethod
+    def forward(ctx, volume, coords, radius):
+        ctx.save_for_backward(volume, coords)
+        ctx.radius = radius
+        corr, = sampler.forward(volume, coords, radius)
+        return corr
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        volume, coords = ctx.saved_tensors
+        grad_output = grad_output.contiguous()
+        grad_volume, = sampler.backward(volume, coords, grad_output, ctx.radius)
+        return grad_volume, None, None

@@ -1,0 +1,289 @@
+// Per-iteration correlation lookup, forward and adjoint, over the skewed pyramid.
+//
+// Replaces core/corr.py:127-146 (reg), core/corr.py:44-51 + sampler/sampler_kernel.cu:19-105
+// (reg_cuda) of the reference.  One launch covers all levels.  A wave owns 64 consecutive
+// pixels of one image row; for a fixed tap those pixels read one or two skew rows of the
+// level at consecutive addresses (rc_layout), so the gather coalesces into full lines
+// whenever the disparity is locally smooth.  Outputs are written per channel plane, 256 B
+// per wave store.
+#include "rc_common.h"
+
+namespace {
+
+constexpr int LK_THREADS = 256;  // 4 waves, each its own 64-pixel chunk
+
+template <typename VT> __device__ __forceinline__ float ld_vol(const VT* p) { return rc_to_float(*p); }
+
+// One level of the forward lookup for one pixel.  R is the compile-time radius.
+template <typename VT, int R, int MODE>
+__device__ __forceinline__ void lookup_level(const VT* __restrict__ lvl_row0, int pitch, int Wi,
+                                             int qm, float xi, float* __restrict__ outp,
+                                             int64_t out_cstride) {
+  constexpr int NT = 2 * R + 1;
+  const float xf = floorf(xi);
+  const float a = xi - xf;
+  const int base = rc_safe_int(xf) - R;
+
+  float v[NT + 1];
+#pragma unroll
+  for (int j = 0; j <= NT; ++j) {
+    const int w2 = base + j;
+    const bool ok = (unsigned)w2 < (unsigned)Wi;
+    int s = qm - w2;
+    s += (s < 0) ? Wi : 0;
+    v[j] = ok ? ld_vol(lvl_row0 + (int64_t)s * pitch) : 0.f;
+  }
+
+  if (MODE == RC_COORD_EXACT) {
+    const float b = 1.0f - a;
+#pragma unroll
+    for (int k = 0; k < NT; ++k) outp[k * out_cstride] = v[k] * b + v[k + 1] * a;
+  } else {
+    const float wm1 = (float)(Wi - 1);
+    int i0[NT];
+    float w0[NT], w1[NT];
+    bool odd = false;
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+      rc_gridsample_coords(xi, k - R, wm1, &i0[k], &w0[k], &w1[k]);
+      odd |= (i0[k] != base + k);
+    }
+    if (__builtin_expect(__any(odd), 0)) {
+      // the fp32 round trip moved some tap across an integer: fetch those taps directly
+#pragma unroll
+      for (int k = 0; k < NT; ++k) {
+        float va = v[k], vb = v[k + 1];
+        if (i0[k] != base + k) {
+          const int wa = i0[k], wb = i0[k] + 1;
+          int sa = qm - wa, sb = qm - wb;
+          sa += (sa < 0) ? Wi : 0;
+          sb += (sb < 0) ? Wi : 0;
+          va = ((unsigned)wa < (unsigned)Wi) ? ld_vol(lvl_row0 + (int64_t)sa * pitch) : 0.f;
+          vb = ((unsigned)wb < (unsigned)Wi) ? ld_vol(lvl_row0 + (int64_t)sb * pitch) : 0.f;
+        }
+        outp[k * out_cstride] = va * w0[k] + vb * w1[k];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NT; ++k) outp[k * out_cstride] = v[k] * w0[k] + v[k + 1] * w1[k];
+    }
+  }
+}
+
+template <typename VT, int R, int MODE>
+__global__ __launch_bounds__(LK_THREADS) void lookup_fwd_kernel(const VT* __restrict__ vol,
+                                                                rc_dev_layout lay,
+                                                                const float* __restrict__ coords,
+                                                                int coords_channels,
+                                                                float* __restrict__ out,
+                                                                int chunks_per_row, int n_items) {
+  constexpr int NT = 2 * R + 1;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int item = blockIdx.x * (LK_THREADS / 64) + wave;  // (row, 64-pixel chunk)
+  if (item >= n_items) return;
+  const int bh = item / chunks_per_row;
+  const int w1 = (item - bh * chunks_per_row) * 64 + lane;
+  if (w1 >= lay.W1) return;
+  const int b = bh / lay.H, h = bh - b * lay.H;
+  const int64_t HW = (int64_t)lay.H * lay.W1;
+
+  const float x = coords[((int64_t)b * coords_channels) * HW + (int64_t)h * lay.W1 + w1];
+  float* outp = out + ((int64_t)b * lay.L * NT) * HW + (int64_t)h * lay.W1 + w1;
+
+  float inv = 1.0f;
+  for (int i = 0; i < lay.L; ++i) {
+    const int Wi = lay.width[i];
+    const int qm = (w1 >> i) % Wi;
+    const VT* row0 = vol + lay.offset[i] + ((int64_t)bh * Wi) * lay.pitch + w1;
+    lookup_level<VT, R, MODE>(row0, lay.pitch, Wi, qm, x * inv, outp + (int64_t)i * NT * HW, HW);
+    inv *= 0.5f;
+  }
+}
+
+// Adjoint: grad_vol (float pyramid) += scatter of grad_out.  The pixel owns column w1 of every
+// skew row, so plain read-modify-write is race free.
+template <int R, int MODE>
+__global__ __launch_bounds__(LK_THREADS) void lookup_bwd_kernel(const float* __restrict__ coords,
+                                                                int coords_channels,
+                                                                const float* __restrict__ gout,
+                                                                float* __restrict__ gvol,
+                                                                rc_dev_layout lay, int chunks_per_row,
+                                                                int n_items) {
+  constexpr int NT = 2 * R + 1;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int item = blockIdx.x * (LK_THREADS / 64) + wave;
+  if (item >= n_items) return;
+  const int bh = item / chunks_per_row;
+  const int w1 = (item - bh * chunks_per_row) * 64 + lane;
+  if (w1 >= lay.W1) return;
+  const int b = bh / lay.H, h = bh - b * lay.H;
+  const int64_t HW = (int64_t)lay.H * lay.W1;
+
+  const float x = coords[((int64_t)b * coords_channels) * HW + (int64_t)h * lay.W1 + w1];
+  const float* gp = gout + ((int64_t)b * lay.L * NT) * HW + (int64_t)h * lay.W1 + w1;
+
+  float inv = 1.0f;
+  for (int i = 0; i < lay.L; ++i) {
+    const int Wi = lay.width[i];
+    const int qm = (w1 >> i) % Wi;
+    float* row0 = gvol + lay.offset[i] + ((int64_t)bh * Wi) * lay.pitch + w1;
+    const float xi = x * inv;
+    inv *= 0.5f;
+    const float xf = floorf(xi);
+    const float a = xi - xf;
+    const int base = rc_safe_int(xf) - R;
+
+    float g[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) g[k] = gp[((int64_t)i * NT + k) * HW];
+
+    float t[NT + 1];
+#pragma unroll
+    for (int j = 0; j <= NT; ++j) t[j] = 0.f;
+
+    if (MODE == RC_COORD_EXACT) {
+      const float bw = 1.0f - a;
+#pragma unroll
+      for (int k = 0; k < NT; ++k) {
+        t[k] += g[k] * bw;
+        t[k + 1] += g[k] * a;
+      }
+    } else {
+      const float wm1 = (float)(Wi - 1);
+#pragma unroll
+      for (int k = 0; k < NT; ++k) {
+        int i0;
+        float w0, w1w;
+        rc_gridsample_coords(xi, k - R, wm1, &i0, &w0, &w1w);
+        if (i0 == base + k) {
+          t[k] += g[k] * w0;
+          t[k + 1] += g[k] * w1w;
+        } else {
+          // rare: this tap landed on a neighbouring integer; update its two cells directly
+          const int wa = i0, wb = i0 + 1;
+          if ((unsigned)wa < (unsigned)Wi) {
+            int s = qm - wa;
+            s += (s < 0) ? Wi : 0;
+            row0[(int64_t)s * lay.pitch] += g[k] * w0;
+          }
+          if ((unsigned)wb < (unsigned)Wi) {
+            int s = qm - wb;
+            s += (s < 0) ? Wi : 0;
+            row0[(int64_t)s * lay.pitch] += g[k] * w1w;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j <= NT; ++j) {
+      const int w2 = base + j;
+      if ((unsigned)w2 < (unsigned)Wi) {
+        int s = qm - w2;
+        s += (s < 0) ? Wi : 0;
+        row0[(int64_t)s * lay.pitch] += t[j];
+      }
+    }
+  }
+}
+
+template <typename VT, int R>
+int launch_fwd(const void* vol, const rc_dev_layout& d, const float* coords, int cc, float* out,
+               int mode, hipStream_t st) {
+  const int chunks = (d.W1 + 63) / 64;
+  const int64_t items64 = (int64_t)d.B * d.H * chunks;
+  const int n_items = (int)items64;
+  const int blocks = (n_items + (LK_THREADS / 64) - 1) / (LK_THREADS / 64);
+  if (mode == RC_COORD_EXACT)
+    hipLaunchKernelGGL((lookup_fwd_kernel<VT, R, RC_COORD_EXACT>), dim3(blocks), dim3(LK_THREADS), 0, st,
+                       (const VT*)vol, d, coords, cc, out, chunks, n_items);
+  else
+    hipLaunchKernelGGL((lookup_fwd_kernel<VT, R, RC_COORD_GRIDSAMPLE>), dim3(blocks), dim3(LK_THREADS), 0,
+                       st, (const VT*)vol, d, coords, cc, out, chunks, n_items);
+  return rc_check_launch("rc_lookup_fwd");
+}
+
+template <typename VT>
+int dispatch_fwd_radius(const void* vol, const rc_dev_layout& d, const float* coords, int cc, float* out,
+                        int radius, int mode, hipStream_t st) {
+  switch (radius) {
+    case 1: return launch_fwd<VT, 1>(vol, d, coords, cc, out, mode, st);
+    case 2: return launch_fwd<VT, 2>(vol, d, coords, cc, out, mode, st);
+    case 3: return launch_fwd<VT, 3>(vol, d, coords, cc, out, mode, st);
+    case 4: return launch_fwd<VT, 4>(vol, d, coords, cc, out, mode, st);
+    case 5: return launch_fwd<VT, 5>(vol, d, coords, cc, out, mode, st);
+    case 6: return launch_fwd<VT, 6>(vol, d, coords, cc, out, mode, st);
+    case 7: return launch_fwd<VT, 7>(vol, d, coords, cc, out, mode, st);
+    case 8: return launch_fwd<VT, 8>(vol, d, coords, cc, out, mode, st);
+  }
+  rc_set_error("radius %d outside 1..%d", radius, RC_MAX_RADIUS);
+  return RC_EUNSUPPORTED;
+}
+
+template <int R>
+int launch_bwd(const float* coords, int cc, const float* gout, float* gvol, const rc_dev_layout& d,
+               int mode, hipStream_t st) {
+  const int chunks = (d.W1 + 63) / 64;
+  const int n_items = (int)((int64_t)d.B * d.H * chunks);
+  const int blocks = (n_items + (LK_THREADS / 64) - 1) / (LK_THREADS / 64);
+  if (mode == RC_COORD_EXACT)
+    hipLaunchKernelGGL((lookup_bwd_kernel<R, RC_COORD_EXACT>), dim3(blocks), dim3(LK_THREADS), 0, st, coords,
+                       cc, gout, gvol, d, chunks, n_items);
+  else
+    hipLaunchKernelGGL((lookup_bwd_kernel<R, RC_COORD_GRIDSAMPLE>), dim3(blocks), dim3(LK_THREADS), 0, st,
+                       coords, cc, gout, gvol, d, chunks, n_items);
+  return rc_check_launch("rc_lookup_bwd");
+}
+
+int check_common(const rc_layout* lay, const void* a, const void* b, const void* c, int cc, int radius,
+                 int mode) {
+  RC_REQUIRE(lay && a && b && c, RC_EINVAL, "null pointer argument");
+  int rc = rc_validate_layout(lay);
+  if (rc) return rc;
+  RC_REQUIRE(cc >= 1, RC_EINVAL, "coords must have at least one channel (got %d)", cc);
+  RC_REQUIRE(radius >= 1 && radius <= RC_MAX_RADIUS, RC_EUNSUPPORTED, "radius %d outside 1..%d", radius,
+             RC_MAX_RADIUS);
+  RC_REQUIRE(mode == RC_COORD_EXACT || mode == RC_COORD_GRIDSAMPLE, RC_EINVAL, "bad coord_mode %d", mode);
+  if (mode == RC_COORD_GRIDSAMPLE)
+    RC_REQUIRE(lay->width[lay->L - 1] >= 2, RC_EINVAL,
+               "grid_sample coordinates need every level at least 2 wide (W2=%lld, L=%d)",
+               (long long)lay->W2, lay->L);
+  RC_REQUIRE((int64_t)lay->B * lay->H * ((lay->W1 + 63) / 64) < (1ll << 31), RC_EINVAL, "too many pixels");
+  return RC_OK;
+}
+
+}  // namespace
+
+extern "C" int rc_lookup_fwd(const void* vol, const rc_layout* lay, int vol_dtype, const float* coords,
+                             int coords_channels, float* out, int radius, int coord_mode, void* stream) {
+  int rc = check_common(lay, vol, coords, out, coords_channels, radius, coord_mode);
+  if (rc) return rc;
+  const rc_dev_layout d = rc_to_dev(lay);
+  hipStream_t st = (hipStream_t)stream;
+  switch (vol_dtype) {
+    case RC_F32: return dispatch_fwd_radius<float>(vol, d, coords, coords_channels, out, radius, coord_mode, st);
+    case RC_F16: return dispatch_fwd_radius<rc_half>(vol, d, coords, coords_channels, out, radius, coord_mode, st);
+    case RC_BF16: return dispatch_fwd_radius<rc_bf16>(vol, d, coords, coords_channels, out, radius, coord_mode, st);
+  }
+  rc_set_error("unknown vol_dtype %d", vol_dtype);
+  return RC_EUNSUPPORTED;
+}
+
+extern "C" int rc_lookup_bwd(const float* coords, int coords_channels, const float* grad_out,
+                             float* grad_vol, const rc_layout* lay, int radius, int coord_mode,
+                             void* stream) {
+  int rc = check_common(lay, coords, grad_out, grad_vol, coords_channels, radius, coord_mode);
+  if (rc) return rc;
+  const rc_dev_layout d = rc_to_dev(lay);
+  hipStream_t st = (hipStream_t)stream;
+  switch (radius) {
+    case 1: return launch_bwd<1>(coords, coords_channels, grad_out, grad_vol, d, coord_mode, st);
+    case 2: return launch_bwd<2>(coords, coords_channels, grad_out, grad_vol, d, coord_mode, st);
+    case 3: return launch_bwd<3>(coords, coords_channels, grad_out, grad_vol, d, coord_mode, st);
+    case 4: return launch_bwd<4>(coords, coords_channels, grad_out, grad_vol, d, coord_mode, st);
+    case 5: return launch_bwd<5>(coords, coords_channels, grad_out, grad_vol, d, coord_mode, st);
+    case 6: return launch_bwd<6>(coords, coords_channels, grad_out, grad_vol, d, coord_mode, st);
+    case 7: return launch_bwd<7>(coords, coords_channels, grad_out, grad_vol, d, coord_mode, st);
+    case 8: return launch_bwd<8>(coords, coords_channels, grad_out, grad_vol, d, coord_mode, st);
+  }
+  return RC_EUNSUPPORTED;
+}

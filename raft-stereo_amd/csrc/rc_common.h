@@ -1,0 +1,110 @@
+// Shared host/device helpers for libraftcorr_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/raftcorr.h"
+
+// ---------------------------------------------------------------- host side: errors
+void rc_set_error(const char* fmt, ...);
+int rc_check_launch(const char* what);
+
+#define RC_REQUIRE(cond, code, ...)          \
+  do {                                       \
+    if (!(cond)) {                           \
+      rc_set_error(__VA_ARGS__);             \
+      return (code);                         \
+    }                                        \
+  } while (0)
+
+// ---------------------------------------------------------------- element types
+typedef _Float16 rc_half;
+typedef __bf16 rc_bf16;
+
+template <typename T> struct rc_traits;
+template <> struct rc_traits<float> { static constexpr int id = RC_F32; };
+template <> struct rc_traits<rc_half> { static constexpr int id = RC_F16; };
+template <> struct rc_traits<rc_bf16> { static constexpr int id = RC_BF16; };
+
+__device__ __forceinline__ float rc_to_float(float v) { return v; }
+__device__ __forceinline__ float rc_to_float(rc_half v) { return (float)v; }
+__device__ __forceinline__ float rc_to_float(rc_bf16 v) { return (float)v; }
+
+template <typename T> __device__ __forceinline__ T rc_from_float(float v);
+template <> __device__ __forceinline__ float rc_from_float<float>(float v) { return v; }
+template <> __device__ __forceinline__ rc_half rc_from_float<rc_half>(float v) { return (rc_half)v; }
+template <> __device__ __forceinline__ rc_bf16 rc_from_float<rc_bf16>(float v) { return (rc_bf16)v; }
+
+// round through the storage type (identity for float)
+template <typename T> __device__ __forceinline__ float rc_round_as(float v) {
+  return rc_to_float(rc_from_float<T>(v));
+}
+
+// ---------------------------------------------------------------- pyramid layout on device
+struct rc_dev_layout {
+  int32_t L;
+  int32_t pitch;
+  int32_t H, W1, W2;
+  int32_t B;
+  int32_t width[RC_MAX_LEVELS];
+  int64_t offset[RC_MAX_LEVELS];
+};
+
+static inline rc_dev_layout rc_to_dev(const rc_layout* lay) {
+  rc_dev_layout d;
+  d.L = lay->L;
+  d.pitch = lay->pitch;
+  d.H = (int32_t)lay->H;
+  d.W1 = (int32_t)lay->W1;
+  d.W2 = (int32_t)lay->W2;
+  d.B = (int32_t)lay->B;
+  for (int i = 0; i < RC_MAX_LEVELS; ++i) {
+    d.width[i] = lay->width[i];
+    d.offset[i] = lay->offset[i];
+  }
+  return d;
+}
+
+int rc_validate_layout(const rc_layout* lay);
+
+// ---------------------------------------------------------------- tap coordinates
+// Non-negative (a mod m) for m > 0.
+__device__ __forceinline__ int rc_pmod(int a, int m) {
+  int r = a % m;
+  return r < 0 ? r + m : r;
+}
+
+// float -> int that maps nan / huge values to a far-out-of-range index (all taps zero)
+__device__ __forceinline__ int rc_safe_int(float f) {
+  return (fabsf(f) < 1.0e8f) ? (int)f : -(1 << 28);
+}
+
+// EXACT coordinates (sampler_kernel.cu:42-57): base tap index and lerp weight for one level.
+__device__ __forceinline__ void rc_exact_coords(float x, float inv_scale, int radius, int* base,
+                                                float* a) {
+  const float xi = x * inv_scale;  // exact: division by a power of two
+  const float xf = floorf(xi);
+  *a = xi - xf;
+  *base = rc_safe_int(xf) - radius;
+}
+
+// GRIDSAMPLE coordinates of tap k (core/corr.py:137, core/utils/utils.py:63, grid_sample with
+// align_corners=True).  Every operation rounds in fp32 exactly as the reference's tensors do;
+// no contraction is possible here (no multiply feeds an add).
+__device__ __forceinline__ void rc_gridsample_coords(float xi, int k_minus_r, float wm1, int* i0,
+                                                     float* w0, float* w1) {
+  const float p = __fadd_rn(xi, (float)k_minus_r);
+  const float g = __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, p), wm1), 1.0f);
+  const float ix = __fmul_rn(__fmul_rn(__fadd_rn(g, 1.0f), 0.5f), wm1);
+  const float x0 = floorf(ix);
+  *w1 = __fsub_rn(ix, x0);
+  *w0 = __fsub_rn(__fadd_rn(x0, 1.0f), ix);
+  const bool ok = fabsf(x0) < 1.0e8f;
+  *i0 = ok ? (int)x0 : -(1 << 28);
+  if (!ok) {
+    *w0 = 0.f;
+    *w1 = 0.f;
+  }
+}

@@ -1,0 +1,51 @@
+"""Selection of the correlation implementation and work partitioning.
+
+Counterpart of the dispatch in the reference's model driver (core/raft_stereo.py:90-100): a
+string in `args.corr_implementation` picks the block class, `reg`/`alt` style blocks get fp32
+feature maps, the native ones keep the autocast dtype.  The reference's four names are kept as
+keys so that a caller can see what is (not) provided here; only the *_hip entries are
+implemented by this package.
+"""
+import torch
+
+from raft_stereo_amd.corr import CorrBlock1DHip, AltCorrBlock1DHip
+
+HIP_CORR_CHOICES = ("reg_hip", "alt_hip")
+
+# name -> (block class, cast feature maps to fp32 unless mixed precision is on)
+CORR_IMPLEMENTATIONS = {
+    "reg_hip": (CorrBlock1DHip, True),
+    "alt_hip": (AltCorrBlock1DHip, True),
+}
+
+
+def wants_autocast(corr_implementation):
+    """evaluate_stereo.py:230 enables autocast iff the name ends with `_cuda`; the HIP blocks
+    take 16-bit feature maps the same way."""
+    return corr_implementation.endswith("_cuda") or corr_implementation.endswith("_hip")
+
+
+def make_corr_fn(corr_implementation, fmap1, fmap2, radius=4, num_levels=4, mixed_precision=False):
+    """What core/raft_stereo.py:90-100 does for the names this package owns.  Unknown names
+    raise (the reference falls through its if/elif and dies with UnboundLocalError)."""
+    if corr_implementation not in CORR_IMPLEMENTATIONS:
+        raise ValueError(f"corr_implementation {corr_implementation!r} is not provided by raft_stereo_amd; "
+                         f"choices: {sorted(CORR_IMPLEMENTATIONS)}")
+    cls, to_fp32 = CORR_IMPLEMENTATIONS[corr_implementation]
+    if to_fp32 and not mixed_precision:
+        fmap1, fmap2 = fmap1.float(), fmap2.float()
+    return cls(fmap1, fmap2, radius=radius, num_levels=num_levels)
+
+
+def shard_pairs(n_pairs, world_size, rank):
+    """Contiguous batch shard [lo, hi) of image pairs for one rank (no collective: pairs are
+    independent)."""
+    base, rem = divmod(n_pairs, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_rows(height, world_size, rank):
+    """Row-slab [lo, hi) of the feature maps for one rank: 1-D correlation never crosses image
+    rows (core/corr.py:120, sampler_kernel.cu:50), so slabs need no halo and no exchange."""
+    return shard_pairs(height, world_size, rank)

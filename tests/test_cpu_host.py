@@ -1,0 +1,127 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/raftcorr.h
+declares, the layout arithmetic is what the oracle-side un-skew expects, and the host-side
+dispatch / sharding logic (including a 2-rank gloo run) is right.  No compute calls."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from raft_stereo_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "raftcorr.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(rc_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), name
+    assert _lib.lib.rc_version() == 100
+
+
+def test_layout_matches_documented_formula():
+    from raft_stereo_amd._lib import lib, Layout
+    lay = Layout()
+    assert lib.rc_pyramid_layout(8, 96, 312, 312, 4, lay) == 0
+    assert lay.pitch == 320 and list(lay.width) == [312, 156, 78, 39]
+    off = 0
+    for i in range(4):
+        assert lay.offset[i] == off
+        off += 8 * 96 * lay.width[i] * lay.pitch
+    assert lay.total == off
+    assert lib.rc_pyramid_layout(1, 1, 16, 4, 4, lay) != 0          # W2 too small for 4 levels
+    assert b"too small" in lib.rc_last_error_string()
+    assert lib.rc_pyramid_layout(1, 1, 16, 64, 5, lay) != 0         # more levels than compiled
+    assert lib.rc_pyramid_layout(0, 1, 16, 64, 4, lay) != 0
+
+
+def test_null_and_bad_arguments_are_rejected_without_a_gpu():
+    from raft_stereo_amd._lib import lib, Layout
+    lay = Layout()
+    lib.rc_pyramid_layout(1, 2, 64, 64, 4, lay)
+    assert lib.rc_lookup_fwd(None, lay, 0, None, 2, None, 4, 0, None) == -1
+    assert lib.rc_build_pyramid(None, None, None, lay, 256, 0, 0, None) == -1
+    lay.pitch = 100                                                  # forged layout
+    assert lib.rc_lookup_fwd(1, lay, 0, 1, 2, 1, 4, 0, None) == -1
+    assert b"rc_pyramid_layout" in lib.rc_last_error_string()
+
+
+def test_skew_index_is_a_bijection():
+    """Every (w1, w2) of a level maps to its own (skew row, column) cell."""
+    for W1, W2, i in [(40, 45, 0), (40, 45, 2), (72, 200, 3), (200, 45, 1), (33, 33, 1)]:
+        Wi = W2 >> i
+        w1 = np.arange(W1)[:, None]
+        w2 = np.arange(Wi)[None, :]
+        s = ((w1 >> i) - w2) % Wi
+        cells = set(zip(s.ravel().tolist(), np.broadcast_to(w1, s.shape).ravel().tolist()))
+        assert len(cells) == W1 * Wi
+
+
+def test_dispatch_and_shards():
+    import raft_stereo_amd as R
+    assert set(R.HIP_CORR_CHOICES) == {"reg_hip", "alt_hip"} == set(R.CORR_IMPLEMENTATIONS)
+    assert R.wants_autocast("reg_hip") and R.wants_autocast("reg_cuda") and not R.wants_autocast("reg")
+    for n, ws in [(64, 8), (504, 8), (7, 3), (2, 4)]:
+        spans = [R.shard_pairs(n, ws, r) for r in range(ws)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= 1
+    assert R.shard_rows(504, 8, 3) == (189, 252)
+
+
+def test_blocks_refuse_cpu_tensors():
+    import torch
+    import raft_stereo_amd as R
+    f = torch.randn(1, 32, 2, 32)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        R.CorrBlock1DHip(f, f)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        R.AltCorrBlock1DHip(f, f)
+
+
+GLOO_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["RC_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+import raft_stereo_amd as R
+from oracle import corr_oracle as O
+dist.init_process_group("gloo")
+rank, ws = dist.get_rank(), dist.get_world_size()
+rng = np.random.default_rng(3)
+B, D, H, W = 5, 16, 6, 24
+f1 = rng.standard_normal((B, D, H, W)).astype(np.float32)
+f2 = rng.standard_normal((B, D, H, W)).astype(np.float32)
+coords = O.synthetic_coords(B, H, W, seed=9)
+full = O.lookup_exact(O.pool_pyramid(O.corr_volume(f1, f2), 3), coords, 2)
+# pair sharding and row-slab sharding both reproduce the unsharded result with no exchange
+lo, hi = R.shard_pairs(B, ws, rank)
+part = O.lookup_exact(O.pool_pyramid(O.corr_volume(f1[lo:hi], f2[lo:hi]), 3), coords[lo:hi], 2)
+assert np.array_equal(part, full[lo:hi])
+r0, r1 = R.shard_rows(H, ws, rank)
+slab = O.lookup_exact(O.pool_pyramid(O.corr_volume(f1[:, :, r0:r1], f2[:, :, r0:r1]), 3), coords[:, :, r0:r1], 2)
+assert np.allclose(slab, full[:, :, r0:r1], rtol=0, atol=1e-6)
+# the only cross-rank traffic of the bench: max-over-ranks of the elapsed time, sum of units
+t = torch.tensor([float(rank + 1)]); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+n = torch.tensor([float(hi - lo)]); dist.all_reduce(n, op=dist.ReduceOp.SUM)
+assert t.item() == ws and n.item() == B
+dist.barrier()
+print("rank", rank, "ok")
+'''
+
+
+def test_two_rank_gloo_sharding(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(GLOO_WORKER)
+    env = dict(os.environ, RC_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert res.stdout.count("ok") == 2

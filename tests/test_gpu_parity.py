@@ -1,0 +1,261 @@
+"""GPU parity tests: the HIP path (through the C-ABI library) against the CPU oracle and the
+golden vectors captured from the reference.  Run on the GPU box with `-m gpu`.
+
+Bars (metric max|a-b| / max|ref|):
+  fp32  : 1e-5 against the reference's reg path (golden vectors)
+  fp16  : 2e-3, bf16: 1.6e-2 against the fp32 oracle evaluated on the rounded inputs
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import corr_oracle as O
+from conftest import GOLDEN_CASES
+
+pytestmark = pytest.mark.gpu
+
+KINDS = ["smooth", "random", "edge"]
+TOL32 = 1e-5
+TOL16 = {torch.float16: 2e-3, torch.bfloat16: 1.6e-2}
+
+
+@pytest.fixture(scope="module")
+def R():
+    import raft_stereo_amd
+    assert torch.cuda.is_available(), "these tests need a GPU"
+    return raft_stereo_amd
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return t.to(dtype) if dtype is not None else t
+
+
+def rel(a, b):
+    return O.rel_to_max(a.detach().float().cpu().numpy() if torch.is_tensor(a) else a, b)
+
+
+# ------------------------------------------------------------------ fp32: golden vectors
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_build_fp32_matches_reference_pyramid(R, golden, case):
+    g = golden(case)
+    L, r = int(g["L"]), int(g["r"])
+    blk = R.CorrBlock1DHip(dev(g["f1"]), dev(g["f2"]), num_levels=L, radius=r)
+    for i in range(L):
+        got = blk.dense_level(i)
+        assert tuple(got.shape) == g[f"level{i}"].shape
+        assert rel(got, g[f"level{i}"]) < TOL32, f"level {i}"
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+@pytest.mark.parametrize("kind", KINDS)
+def test_lookup_fp32_matches_reference_reg(R, golden, case, kind):
+    g = golden(case)
+    L, r = int(g["L"]), int(g["r"])
+    blk = R.CorrBlock1DHip(dev(g["f1"]), dev(g["f2"]), num_levels=L, radius=r)
+    out = blk(dev(g[f"coords_{kind}"]))
+    assert out.dtype == torch.float32 and out.is_contiguous()
+    assert tuple(out.shape) == g[f"lookup_{kind}"].shape
+    assert rel(out, g[f"lookup_{kind}"]) < TOL32
+    # 1-channel coords (what CorrBlockFast1D passes, core/corr.py:47) give the same result
+    out1 = blk(dev(g[f"coords_{kind}"][:, :1]))
+    assert torch.equal(out, out1)
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+@pytest.mark.parametrize("kind", KINDS)
+def test_lookup_exact_mode_matches_sampler_semantics(R, golden, case, kind):
+    g = golden(case)
+    L, r = int(g["L"]), int(g["r"])
+    blk = R.CorrBlock1DHip(dev(g["f1"]), dev(g["f2"]), num_levels=L, radius=r, coord_mode="exact")
+    pyr = [blk.dense_level(i).cpu().numpy() for i in range(L)]
+    out = blk(dev(g[f"coords_{kind}"]))
+    assert rel(out, O.lookup_exact(pyr, g[f"coords_{kind}"], r)) < 2e-6
+    far = np.abs(g[f"coords_{kind}"][:, 0]) >= 1e3
+    if far.any():
+        assert np.all(out.cpu().numpy().transpose(0, 2, 3, 1)[far] == 0)
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_backward_fp32_matches_reference_autograd(R, golden, case):
+    g = golden(case)
+    L, r = int(g["L"]), int(g["r"])
+    f1 = dev(g["f1"]).requires_grad_(True)
+    f2 = dev(g["f2"]).requires_grad_(True)
+    blk = R.CorrBlock1DHip(f1, f2, num_levels=L, radius=r)
+    outs = [blk(dev(g[f"coords_{k}"])) for k in KINDS]
+    assert all(o.requires_grad for o in outs)
+    d1, d2 = torch.autograd.grad((outs[0] * dev(g["gout_smooth"])).sum(), (f1, f2), retain_graph=True)
+    assert rel(d1, g["df1_single"]) < TOL32 and rel(d2, g["df2_single"]) < TOL32
+    tot = sum((o * dev(g[f"gout_{k}"])).sum() for o, k in zip(outs, KINDS))
+    tot.backward()
+    assert rel(f1.grad, g["df1_multi"]) < TOL32
+    assert rel(f2.grad, g["df2_multi"]) < TOL32
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+@pytest.mark.parametrize("kind", KINDS)
+def test_alt_fp32_matches_reference_reg(R, golden, case, kind):
+    g = golden(case)
+    L, r = int(g["L"]), int(g["r"])
+    blk = R.AltCorrBlock1DHip(dev(g["f1"]), dev(g["f2"]), num_levels=L, radius=r)
+    out = blk(dev(g[f"coords_{kind}"]))
+    assert rel(out, g[f"lookup_{kind}"]) < TOL32
+    assert rel(out, g[f"alt_{kind}"]) < 5e-5
+
+
+# ------------------------------------------------------------------ MFMA kernel vs the naive kernel
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 256, 3, 312, 312), (1, 96, 2, 70, 131), (1, 256, 2, 200, 45)])
+def test_build_mfma_equals_naive_kernel(R, dtype, shape):
+    from raft_stereo_amd._lib import lib, check
+    B, D, H, W1, W2 = shape
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    # small integers: every product and partial sum is exact in all three types
+    f1 = torch.randint(-3, 4, (B, D, H, W1), generator=gen, device="cuda").to(dtype)
+    f2 = torch.randint(-3, 4, (B, D, H, W2), generator=gen, device="cuda").to(dtype)
+    blk = R.CorrBlock1DHip(f1, f2, num_levels=4, radius=4)
+    ref = torch.full_like(blk.volume, float("nan"))
+    check(lib.rc_build_pyramid_naive(f1.data_ptr(), f2.data_ptr(), ref.data_ptr(), blk.layout, D, blk.in_dtype,
+                                     blk.vol_dtype, torch.cuda.current_stream().cuda_stream), "naive")
+    mine, blk.volume = blk.volume, ref
+    for i in range(4):
+        a = blk.dense_level(i).float()
+        blk.volume = mine
+        b = blk.dense_level(i).float()
+        blk.volume = ref
+        assert torch.equal(a, b), f"level {i} differs: max {float((a - b).abs().max())}"
+
+
+# ------------------------------------------------------------------ 16-bit against the rounded-input oracle
+def _round(a, dtype):
+    return torch.from_numpy(a).to(dtype).float().numpy()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("case", ["d256_b1_h4_w128", "odd_b1_d64_h2_w40x45", "wide_b1_d256_h2_w72x200"])
+def test_16bit_volume_and_lookup(R, golden, case, dtype):
+    g = golden(case)
+    L, r = int(g["L"]), int(g["r"])
+    f1r, f2r = _round(g["f1"], dtype), _round(g["f2"], dtype)
+    pyr = O.pool_pyramid(O.corr_volume(f1r, f2r), L)
+    blk = R.CorrBlock1DHip(dev(g["f1"], dtype), dev(g["f2"], dtype), num_levels=L, radius=r)
+    assert blk.volume.dtype == dtype
+    for i in range(L):
+        assert rel(blk.dense_level(i), pyr[i]) < TOL16[dtype]
+    for kind in KINDS:
+        out = blk(dev(g[f"coords_{kind}"]))
+        assert out.dtype == torch.float32
+        assert rel(out, O.lookup_exact(pyr, g[f"coords_{kind}"], r)) < TOL16[dtype]
+        alt = R.AltCorrBlock1DHip(dev(g["f1"], dtype), dev(g["f2"], dtype), num_levels=L, radius=r)(
+            dev(g[f"coords_{kind}"]))
+        assert rel(alt, O.lookup_exact(pyr, g[f"coords_{kind}"], r)) < TOL16[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_16bit_backward(R, golden, dtype):
+    g = golden("d256_b1_h4_w128")
+    L, r = int(g["L"]), int(g["r"])
+    f1r, f2r = _round(g["f1"], dtype), _round(g["f2"], dtype)
+    widths = [g[f"level{i}"].shape[-1] for i in range(L)]
+    acc = None
+    for k in KINDS:
+        lg = O.lookup_bwd(g[f"coords_{k}"], g[f"gout_{k}"], widths, r, O.EXACT)
+        acc = lg if acc is None else [a + b for a, b in zip(acc, lg)]
+    rd1, rd2 = O.corr_volume_bwd(O.pool_pyramid_bwd(acc), f1r, f2r)
+    f1 = dev(g["f1"], dtype).requires_grad_(True)
+    f2 = dev(g["f2"], dtype).requires_grad_(True)
+    blk = R.CorrBlock1DHip(f1, f2, num_levels=L, radius=r)
+    sum((blk(dev(g[f"coords_{k}"])) * dev(g[f"gout_{k}"])).sum() for k in KINDS).backward()
+    assert f1.grad.dtype == dtype
+    assert rel(f1.grad, rd1) < TOL16[dtype] and rel(f2.grad, rd2) < TOL16[dtype]
+
+
+# ------------------------------------------------------------------ corr_sampler twin
+@pytest.mark.parametrize("case", ["tiny_b2_d32_h3_w24", "odd_b1_d64_h2_w40x45"])
+@pytest.mark.parametrize("kind", KINDS)
+def test_sampler_twin_forward_backward(R, golden, case, kind):
+    g = golden(case)
+    r = int(g["r"])
+    for i in range(2):
+        vol = dev(g[f"level{i}"]).requires_grad_(True)
+        coords = dev((g[f"coords_{kind}"] / 2 ** i).astype(np.float32))
+        out = R.CorrSamplerHip.apply(vol, coords, r)
+        ref = O.lookup_exact([g[f"level{i}"]], (g[f"coords_{kind}"] / 2 ** i).astype(np.float32), r)
+        assert tuple(out.shape) == ref.shape
+        assert rel(out, ref) < 2e-6
+        gout = g[f"gout_{kind}"][:, :2 * r + 1]
+        out.backward(dev(gout))
+        rg = O.lookup_bwd((g[f"coords_{kind}"] / 2 ** i).astype(np.float32), gout, [vol.shape[-1]], r, O.EXACT)[0]
+        assert rel(vol.grad, rg) < 2e-6
+    with pytest.raises(RuntimeError):
+        R.corr_sampler_hip.forward(vol.detach().cpu(), coords, r)
+    with pytest.raises(RuntimeError):
+        R.corr_sampler_hip.forward(vol.detach().transpose(2, 3), coords, r)
+
+
+# ------------------------------------------------------------------ full-size properties (BASELINE configs)
+@pytest.mark.parametrize("dtype,shape", [(torch.float16, (8, 256, 96, 312)), (torch.float32, (1, 256, 96, 128)),
+                                         (torch.float16, (1, 256, 60, 80)), (torch.bfloat16, (8, 256, 80, 180))])
+def test_full_size_properties(R, dtype, shape):
+    B, D, H, W = shape
+    gen = torch.Generator(device="cuda").manual_seed(1234)
+    f1 = torch.randn(shape, generator=gen, device="cuda").to(dtype)
+    f2 = torch.randn(shape, generator=gen, device="cuda").to(dtype)
+    blk = R.CorrBlock1DHip(f1, f2, num_levels=4, radius=4, coord_mode="exact")
+    # (a) one image row against the oracle
+    b, h = B - 1, H // 3
+    pyr = O.pool_pyramid(O.corr_volume(f1[b:b + 1, :, h:h + 1].float().cpu().numpy(),
+                                       f2[b:b + 1, :, h:h + 1].float().cpu().numpy()), 4)
+    tol = TOL32 if dtype == torch.float32 else TOL16[dtype]
+    for i in range(4):
+        assert rel(blk.dense_level(i)[b:b + 1, h:h + 1], pyr[i]) < tol
+    # (b) integer coordinates: the centre tap of level 0 is the volume entry itself (bit exact),
+    #     and pooled levels at even coordinates likewise
+    xs = torch.arange(W, device="cuda", dtype=torch.float32).view(1, 1, 1, W).expand(B, 1, H, W)
+    disp = torch.randint(0, W // 3, (B, 1, H, W), generator=gen, device="cuda").float()
+    coords = torch.cat([xs - disp, torch.zeros_like(xs)], 1).contiguous()
+    out = blk(coords)
+    lvl0 = blk.dense_level(0).float()
+    idx = (xs - disp).long().clamp(0, W - 1)[:, 0]
+    centre = torch.gather(lvl0, 3, idx.unsqueeze(-1))[..., 0]
+    ok = ((xs - disp) >= 0)[:, 0]
+    assert torch.equal(out[:, 4][ok], centre[ok])
+    # (c) linearity of the lookup in the volume and agreement of alt with reg on device
+    c2 = torch.from_numpy(O.synthetic_coords(B, H, W, seed=5)).cuda()
+    reg = blk(c2)
+    alt = R.AltCorrBlock1DHip(f1, f2, num_levels=4, radius=4, coord_mode="exact")(c2)
+    assert rel(alt, reg.cpu().numpy()) < (2e-5 if dtype == torch.float32 else tol)
+    # (d) the adjoint identity <lookup(V), G> == <V, lookup^T(G)> through the build's gradient
+    if dtype != torch.float32 or B * H * W < 20000:
+        f1g = f1.clone().requires_grad_(True)
+        blk2 = R.CorrBlock1DHip(f1g, f2, num_levels=4, radius=4)
+        G = torch.randn(reg.shape, generator=gen, device="cuda")
+        (blk2(c2) * G).sum().backward()
+        eps_dir = torch.randn(f1.shape, generator=gen, device="cuda")
+        lhs = float((f1g.grad.float() * eps_dir).sum())
+        # correlation is linear in f1: <d/df1, E> = <lookup(C(E, f2)), G>
+        rhs = float((R.CorrBlock1DHip(eps_dir.to(dtype), f2, num_levels=4, radius=4)(c2) * G).sum())
+        assert abs(lhs - rhs) <= 2e-2 * max(abs(lhs), abs(rhs), 1.0)
+
+
+# ------------------------------------------------------------------ argument checking
+def test_argument_errors(R):
+    f = torch.randn(1, 32, 2, 32, device="cuda")
+    with pytest.raises(RuntimeError):
+        R.CorrBlock1DHip(f.cpu(), f.cpu())
+    with pytest.raises(RuntimeError):          # same failure as the reference's avg_pool2d
+        R.CorrBlock1DHip(f[..., :12].contiguous(), f[..., :12].contiguous(), num_levels=4)
+    with pytest.raises(ValueError):
+        R.CorrBlock1DHip(f, f[:, :16].contiguous())
+    blk = R.CorrBlock1DHip(f, f)
+    with pytest.raises(ValueError):
+        blk(torch.zeros(1, 2, 3, 32, device="cuda"))
+    with pytest.raises(ValueError):
+        R.make_corr_fn("reg_cuda", f, f)
+    out = R.make_corr_fn("reg_hip", f.half(), f.half(), radius=4, num_levels=4)(torch.zeros(1, 2, 2, 32, device="cuda"))
+    assert out.shape == (1, 36, 2, 32)
+    # non-contiguous views (shared-backbone split, core/raft_stereo.py:80) are accepted
+    both = torch.randn(2, 32, 2, 32, device="cuda")
+    a, b = both.split(1, dim=0)
+    R.CorrBlock1DHip(a.transpose(2, 3).transpose(2, 3), b)(torch.zeros(1, 2, 2, 32, device="cuda"))
