@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""Benchmark of the correlation hot path (BASELINE.json metric), one process per GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over this rank's batch of synthetic feature maps:
+build the pyramid once, then `iters` lookups (what one RAFTStereo.forward does,
+core/raft_stereo.py:100,108-110).  Pairs are independent, so ranks share nothing on the data
+path (weak scaling: every GPU gets the same per-GPU batch); the only collectives are the
+barrier and the max-over-ranks of the elapsed time.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+METRIC = "corr build TFLOP/s + lookup GB/s; stereo pairs/sec at 1/2/4/8 MI355X"
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA16_PEAK_TF = 2500.0        # dense fp16/bf16
+MFMA32_PEAK_TF = 157.3         # f32-input MFMA
+
+# name -> (per-GPU batch, H, W, dtype, iters, impl, train)   feature depth is 256, 4 levels, radius 4
+WORKLOADS = {
+    # BASELINE.json configs[3]: KITTI 375x1242 -> 384x1248 padded, /4, 32 iters, 64 pairs over 8 GPUs
+    "kitti": dict(batch=8, H=96, W=312, dtype="f16", iters=32, impl="reg_hip", train=False),
+    # configs[1]: realtime 480x640, n_downsample 3, 7 iters, fp16
+    "realtime": dict(batch=1, H=60, W=80, dtype="f16", iters=7, impl="reg_hip", train=False),
+    # configs[0]: the reference's CPU-runnable case, 384x512 fp32, 32 iters
+    "cpu_case": dict(batch=1, H=96, W=128, dtype="f32", iters=32, impl="reg_hip", train=False),
+    # configs[2]: SceneFlow training crop 320x720, batch 8, 22 iters, bf16, forward + backward
+    "sceneflow_train": dict(batch=8, H=80, W=180, dtype="bf16", iters=22, impl="reg_hip", train=True),
+    # configs[4]: Middlebury-F 2016x3008 /4, alt (volume never built); row slabs of 63 rows per GPU
+    "middlebury_alt": dict(batch=1, H=63, W=752, dtype="f16", iters=32, impl="alt_hip", train=False),
+    # the whole Middlebury-F frame on one GPU
+    "middlebury_alt_full": dict(batch=1, H=504, W=752, dtype="f16", iters=32, impl="alt_hip", train=False),
+}
+DTYPES = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
+D, LEVELS, RADIUS = 256, 4, 4
+
+
+def synthetic_inputs(cfg, device, seed):
+    """N(0,1) feature maps, piecewise-smooth disparity; all on the GPU before timing."""
+    from oracle.corr_oracle import synthetic_coords   # input generator only (numpy); not the path under test
+    g = torch.Generator(device=device).manual_seed(seed)
+    B, H, W = cfg["batch"], cfg["H"], cfg["W"]
+    f1 = torch.randn((B, D, H, W), generator=g, device=device).to(DTYPES[cfg["dtype"]])
+    f2 = torch.randn((B, D, H, W), generator=g, device=device).to(DTYPES[cfg["dtype"]])
+    coords = torch.from_numpy(synthetic_coords(B, H, W, seed=seed)).to(device)
+    return f1, f2, coords
+
+
+def algorithmic_counts(cfg):
+    """Per-step algorithmic work: build FLOPs/bytes, lookup bytes per launch."""
+    B, H, W = cfg["batch"], cfg["H"], cfg["W"]
+    s = 4 if cfg["dtype"] == "f32" else 2
+    nt = 2 * RADIUS + 1
+    px = B * H * W
+    build_flops = 2.0 * B * H * W * W * D
+    build_bytes = B * H * 2 * W * D * s + B * H * W * W * s * sum(0.5 ** i for i in range(LEVELS))
+    lookup_bytes = px * (LEVELS * (2 * RADIUS + 2) * s + 4 + LEVELS * nt * 4)      # 228 B (16-bit) / 308 B (f32)
+    alt_flops = px * 2.0 * D * LEVELS * (2 * RADIUS + 2)
+    alt_bytes = px * (s * D * (1 + sum(0.5 ** i for i in range(LEVELS))) + LEVELS * nt * 4 + 4)
+    return dict(pixels=px, build_flops=build_flops, build_bytes=build_bytes, lookup_bytes=lookup_bytes,
+                alt_flops=alt_flops, alt_bytes=alt_bytes)
+
+
+class Step:
+    """One pass of the hot path; records HIP events around the build and around the lookups."""
+
+    def __init__(self, cfg, device, seed):
+        import raft_stereo_amd as R
+        self.R, self.cfg = R, cfg
+        self.f1, self.f2, self.coords = synthetic_inputs(cfg, device, seed)
+        self.train = cfg["train"]
+        if self.train:
+            self.f1.requires_grad_(True)
+            self.f2.requires_grad_(True)
+            g = torch.Generator(device=device).manual_seed(seed + 1)
+            self.gout = torch.randn((cfg["batch"], LEVELS * (2 * RADIUS + 1), cfg["H"], cfg["W"]), generator=g,
+                                    device=device)
+        self.cls = R.CORR_IMPLEMENTATIONS[cfg["impl"]][0]
+        self.events = []          # one set of 4 HIP events per recorded step (torch's current stream
+        self.build_ms, self.lookup_ms, self.bwd_ms = [], [], []   # is the stream the kernels run on)
+
+    def run(self, record):
+        cfg = self.cfg
+        if record:
+            self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            self.events.append(self.ev)
+            self.ev[0].record()
+        blk = self.cls(self.f1, self.f2, num_levels=LEVELS, radius=RADIUS)
+        if record:
+            self.ev[1].record()
+        outs = []
+        for _ in range(cfg["iters"]):
+            out = blk(self.coords)
+            if self.train:
+                outs.append(out)
+        if record:
+            self.ev[2].record()
+        if self.train:
+            self.f1.grad = self.f2.grad = None
+            torch.autograd.backward(outs, [self.gout] * len(outs))
+        if record:
+            self.ev[3].record()
+        return out
+
+    def collect(self):
+        """Call after a device synchronize: event times of every recorded step."""
+        for ev in self.events:
+            self.build_ms.append(ev[0].elapsed_time(ev[1]))
+            self.lookup_ms.append(ev[1].elapsed_time(ev[2]))
+            self.bwd_ms.append(ev[2].elapsed_time(ev[3]))
+        self.events = []
+
+
+def cpu_baseline(cfg, budget_s=15.0):
+    """The reference's reg path (torch ops port, oracle/reg_torch.py) on this host's cores, on a
+    bounded sample of the same workload: ONE pair of this shape in fp32, repeated for ~budget_s."""
+    from oracle.reg_torch import time_reg_path
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    if cfg["impl"] == "alt_hip":
+        sample_h = min(cfg["H"], 63)
+    else:
+        sample_h = cfg["H"]
+    n, tb, tl = 0, 0.0, 0.0
+    t0 = time.perf_counter()
+    while True:
+        b, l, used = time_reg_path(1, D, sample_h, cfg["W"], cfg["iters"], LEVELS, RADIUS, threads=threads)
+        n += 1
+        tb += b
+        tl += l
+        if time.perf_counter() - t0 > budget_s or n >= 20:
+            break
+    per_pair = (tb + tl) / n * (cfg["H"] / sample_h)
+    return dict(value=round(1.0 / per_pair, 4), unit="pairs/s", cores=used, kind="port",
+                sample=f"1 pair of the {cfg['H']}x{cfg['W']} workload in fp32 (reg path: einsum + avg_pool2d + "
+                       f"grid_sample, {cfg['iters']} lookups), {n} passes; build {tb / n * 1e3:.1f} ms, "
+                       f"lookups {tl / n * 1e3:.1f} ms per pass")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="kitti", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--adversarial", action="store_true", help="i.i.d. uniform disparity (worst-case gather)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    cfg = dict(WORKLOADS[args.workload])
+    if args.batch:
+        cfg["batch"] = args.batch
+    step = Step(cfg, device, seed=1234 + rank)
+    if args.adversarial:
+        from oracle.corr_oracle import synthetic_coords
+        step.coords = torch.from_numpy(synthetic_coords(cfg["batch"], cfg["H"], cfg["W"], seed=7, adversarial=True)).to(device)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step.run(record=False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step.run(record=True)       # HIP events bracket the build and the lookups of every timed step
+    barrier()
+    elapsed = time.perf_counter() - t0
+    step.collect()                  # event times are read after the timed region
+
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    cnt = algorithmic_counts(cfg)
+    pairs_total = cfg["batch"] * world * args.steps
+    value = pairs_total / elapsed
+    ms_per_step = elapsed / args.steps * 1e3
+    build_ms = float(np.median(step.build_ms))
+    lookup_ms = float(np.median(step.lookup_ms)) / cfg["iters"]        # average per launch
+    is_alt = cfg["impl"] == "alt_hip"
+    if is_alt:
+        ach = cnt["alt_bytes"] / (lookup_ms * 1e-3) / 1e9
+        roof = dict(bound="hbm", kernel="alt_fwd_kernel", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
+                    algorithmic_bytes_per_launch=int(cnt["alt_bytes"]), avg_launch_us=round(lookup_ms * 1e3, 2),
+                    mfma_tflops=round(cnt["alt_flops"] / (lookup_ms * 1e-3) / 1e12, 2))
+    else:
+        ach = cnt["lookup_bytes"] / (lookup_ms * 1e-3) / 1e9
+        roof = dict(bound="hbm", kernel="lookup_fwd_kernel", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
+                    algorithmic_bytes_per_launch=int(cnt["lookup_bytes"]), avg_launch_us=round(lookup_ms * 1e3, 2))
+    extra = dict(lookup_gbps=round(ach, 1), lookup_us=round(lookup_ms * 1e3, 2))
+    if not is_alt:
+        peak = MFMA32_PEAK_TF if cfg["dtype"] == "f32" else MFMA16_PEAK_TF
+        tf = cnt["build_flops"] / (build_ms * 1e-3) / 1e12
+        ai = cnt["build_flops"] / cnt["build_bytes"]
+        hbm_cap_tf = ai * HBM_PEAK_GBS / 1e3
+        extra.update(build_tflops=round(tf, 2), build_ms=round(build_ms, 4), build_frac_mfma=round(tf / peak, 4),
+                     build_gbps=round(cnt["build_bytes"] / (build_ms * 1e-3) / 1e9, 1),
+                     build_frac_of_binding_roof=round(tf / min(peak, hbm_cap_tf), 4),
+                     build_binding_roof="hbm" if hbm_cap_tf < peak else "mfma")
+    else:
+        extra.update(prepare_ms=round(build_ms, 4))
+    if cfg["train"]:
+        extra.update(backward_ms=round(float(np.median(step.bwd_ms)), 4))
+
+    line = {
+        "metric": METRIC, "value": round(value, 3), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic",
+        "config": {"workload": f"{args.workload}: correlation hot path only ({cfg['impl']}: "
+                               f"{'prepare' if is_alt else 'build+pyramid'} + {cfg['iters']} lookups"
+                               f"{' + backward' if cfg['train'] else ''}), fmaps [{cfg['batch']},{D},{cfg['H']},{cfg['W']}] "
+                               f"per GPU, {LEVELS} levels, radius {RADIUS}",
+                   "per_gpu_batch": cfg["batch"], "global_batch": cfg["batch"] * world, "iters": cfg["iters"],
+                   "partition": "image pairs per rank, no data-path collective",
+                   "coords": "adversarial" if args.adversarial else "piecewise-smooth"},
+        "roofline": roof,
+    }
+    line.update(extra)
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
