@@ -60,18 +60,27 @@ enum {
 };
 
 /*
- * Private layout of the correlation pyramid ("skewed", disparity-major):
- * level i holds B*H row-blocks of width[i] skew rows of `pitch` elements;
- * element (b,h,w1,w2) of level i lives at
- *     offset[i] + ((b*H + h) * width[i] + s) * pitch + w1,   s = ((w1 >> i) - w2) mod width[i]
- * so that, for a fixed tap, neighbouring pixels of one image row with similar disparity read
- * consecutive addresses.  Nothing outside this library and its Python wrapper may index it.
+ * Private layout of the correlation pyramid ("blocked skew", disparity-major):
+ * level i of an image row (b,h) is a [widthp[i]][W1] matrix whose row index is the skew
+ *     s = (w2 - (w1 >> i) - 17) mod widthp[i]            (widthp = width rounded up to 8)
+ * i.e. minus the level-i disparity, so neighbouring pixels with similar disparity use the
+ * same skew rows.  Rows are stored in blocks of rb = 16 / element-size rows, interleaved per
+ * pixel: element (b,h,w1,w2) of level i lives at
+ *     offset[i] + (((b*H + h) * (widthp[i]/rb) + s / rb) * pitch + w1) * rb + s % rb
+ * A pixel's 2r+2 taps are then 2-3 aligned 16-byte pieces, and for a fixed piece the pixels of
+ * a wave read one contiguous 1 KiB run (16 bytes per lane).  The constant 17 keeps the zone
+ * where a tap window wraps around the modulus at disparities of -12..-21 level-i pixels, and
+ * makes the rows a build tile completes per chunk start on a block boundary.
+ * Nothing outside this library and its Python wrapper may index the pyramid.
  */
 typedef struct rc_layout {
   int64_t B, H, W1, W2;
   int32_t L;                        /* levels stored (= levels ever read, corr.py:133-134) */
-  int32_t pitch;                    /* W1 rounded up to a multiple of 64 elements */
+  int32_t pitch;                    /* W1 rounded up to a multiple of 64 pixels */
+  int32_t rb;                       /* skew rows per 16-byte block: 8 (f16/bf16) or 4 (f32) */
+  int32_t dtype;                    /* element type the layout was made for */
   int32_t width[RC_MAX_LEVELS];     /* W2 >> i */
+  int32_t widthp[RC_MAX_LEVELS];    /* width rounded up to a multiple of 8 */
   int64_t offset[RC_MAX_LEVELS];    /* element offset of level i */
   int64_t total;                    /* elements in the whole pyramid */
 } rc_layout;
@@ -79,41 +88,43 @@ typedef struct rc_layout {
 int rc_version(void);
 const char* rc_last_error_string(void);
 
-/* Fills *out; RC_EINVAL if W2 >> (L-1) < 1 or any size is non-positive. */
-int rc_pyramid_layout(int64_t B, int64_t H, int64_t W1, int64_t W2, int L, rc_layout* out);
+/* Fills *out for a pyramid of `dtype` elements; RC_EINVAL if W2 >> (L-1) < 1 or any size is
+ * non-positive.  A float gradient pyramid needs its own layout (dtype RC_F32). */
+int rc_pyramid_layout(int64_t B, int64_t H, int64_t W1, int64_t W2, int L, int dtype,
+                      rc_layout* out);
 
 /*
  * Build all levels of the pyramid: C = f1^T f2 / sqrt(D) per image row, then the pairwise
  * mean chain, written in the private layout.  f1: [B,D,H,W1], f2: [B,D,H,W2] contiguous
- * NCHW of `in_dtype`; vol: lay->total elements of `vol_dtype`.
+ * NCHW of `in_dtype`; vol: lay->total elements of lay->dtype.
  * Arithmetic: RC_F32 inputs use the exact-f32 MFMA (v_mfma_f32_16x16x4_f32), RC_F16/RC_BF16
  * inputs the 16x16x32 f16/bf16 MFMA with f32 accumulation; levels >= 1 are means of the
  * already-rounded lower level (what avg_pool2d on a 16-bit volume does, corr.py:42).
  * Supported: (in,vol) = (F32,F32), (F16,F16), (BF16,BF16), (F16|BF16, F32).
  */
 int rc_build_pyramid(const void* f1, const void* f2, void* vol, const rc_layout* lay,
-                     int64_t D, int in_dtype, int vol_dtype, void* stream);
+                     int64_t D, int in_dtype, void* stream);
 /* Diagnostic twin (no counterpart in the reference): same contract, but always runs the
  * one-thread-per-element kernels that rc_build_pyramid only falls back to for D > 256.
  * Used by the GPU tests as an on-device cross-check of the MFMA kernel. */
 int rc_build_pyramid_naive(const void* f1, const void* f2, void* vol, const rc_layout* lay,
-                           int64_t D, int in_dtype, int vol_dtype, void* stream);
+                           int64_t D, int in_dtype, void* stream);
 
 /*
  * Lookup, all levels in one launch.
  * coords: float [B, coords_channels, H, W1] (channel 0 = x; other channels ignored);
  * out:    float [B, L*(2r+1), H, W1], channel = level*(2r+1) + tap  (corr.py:145-146).
  */
-int rc_lookup_fwd(const void* vol, const rc_layout* lay, int vol_dtype, const float* coords,
+int rc_lookup_fwd(const void* vol, const rc_layout* lay, const float* coords,
                   int coords_channels, float* out, int radius, int coord_mode, void* stream);
 
 /*
- * Adjoint of rc_lookup_fwd w.r.t. the pyramid.  grad_vol is a float pyramid in the same
- * layout that is ACCUMULATED into (+=): zero it once per forward pass, then call this once
+ * Adjoint of rc_lookup_fwd w.r.t. the pyramid.  grad_vol is a float pyramid (glay->dtype ==
+ * RC_F32) that is ACCUMULATED into (+=): zero it once per forward pass, then call this once
  * per lookup.  Calls on one stream are ordered; no atomics are used (a pixel owns its column).
  */
 int rc_lookup_bwd(const float* coords, int coords_channels, const float* grad_out,
-                  float* grad_vol, const rc_layout* lay, int radius, int coord_mode,
+                  float* grad_vol, const rc_layout* glay, int radius, int coord_mode,
                   void* stream);
 
 /*
@@ -121,8 +132,8 @@ int rc_lookup_bwd(const float* coords, int coords_channels, const float* grad_ou
  * feature maps: df1[b,d,h,w1] = sum_w2 dC f2 / sqrt(D), df2[b,d,h,w2] = sum_w1 dC f1 / sqrt(D).
  * df1/df2 have the dtype and shape of f1/f2.  `work` is scratch of rc_build_bwd_work_bytes().
  */
-int64_t rc_build_bwd_work_bytes(const rc_layout* lay, int in_dtype);
-int rc_build_bwd(const float* grad_vol, const rc_layout* lay, const void* f1, const void* f2,
+int64_t rc_build_bwd_work_bytes(const rc_layout* glay, int in_dtype);
+int rc_build_bwd(const float* grad_vol, const rc_layout* glay, const void* f1, const void* f2,
                  void* df1, void* df2, int64_t D, int in_dtype, void* work, void* stream);
 
 /*

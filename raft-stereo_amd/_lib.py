@@ -10,6 +10,7 @@ RC_MAX_LEVELS = 4
 RC_MAX_RADIUS = 8
 RC_F32, RC_F16, RC_BF16 = 0, 1, 2
 RC_COORD_EXACT, RC_COORD_GRIDSAMPLE = 0, 1
+RC_SKEW = 17
 
 LIB_NAME = "libraftcorr_hip.so"
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
@@ -18,8 +19,9 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 class Layout(C.Structure):
     """rc_layout of include/raftcorr.h."""
     _fields_ = [("B", C.c_int64), ("H", C.c_int64), ("W1", C.c_int64), ("W2", C.c_int64),
-                ("L", C.c_int32), ("pitch", C.c_int32),
+                ("L", C.c_int32), ("pitch", C.c_int32), ("rb", C.c_int32), ("dtype", C.c_int32),
                 ("width", C.c_int32 * RC_MAX_LEVELS),
+                ("widthp", C.c_int32 * RC_MAX_LEVELS),
                 ("offset", C.c_int64 * RC_MAX_LEVELS),
                 ("total", C.c_int64)]
 
@@ -42,10 +44,10 @@ _LP, _ALP = C.POINTER(Layout), C.POINTER(AltLayout)
 SIGNATURES = {
     "rc_version": (_I, []),
     "rc_last_error_string": (C.c_char_p, []),
-    "rc_pyramid_layout": (_I, [_L, _L, _L, _L, _I, _LP]),
-    "rc_build_pyramid": (_I, [_P, _P, _P, _LP, _L, _I, _I, _P]),
-    "rc_build_pyramid_naive": (_I, [_P, _P, _P, _LP, _L, _I, _I, _P]),
-    "rc_lookup_fwd": (_I, [_P, _LP, _I, _P, _I, _P, _I, _I, _P]),
+    "rc_pyramid_layout": (_I, [_L, _L, _L, _L, _I, _I, _LP]),
+    "rc_build_pyramid": (_I, [_P, _P, _P, _LP, _L, _I, _P]),
+    "rc_build_pyramid_naive": (_I, [_P, _P, _P, _LP, _L, _I, _P]),
+    "rc_lookup_fwd": (_I, [_P, _LP, _P, _I, _P, _I, _I, _P]),
     "rc_lookup_bwd": (_I, [_P, _I, _P, _P, _LP, _I, _I, _P]),
     "rc_build_bwd_work_bytes": (_L, [_LP, _I]),
     "rc_build_bwd": (_I, [_P, _LP, _P, _P, _P, _P, _L, _I, _P, _P]),

@@ -78,7 +78,7 @@ class _BuildFn(torch.autograd.Function):
         if gvol is None:          # no lookup took part in the loss
             return torch.zeros_like(fmap1), torch.zeros_like(fmap2), None
         df1, df2 = torch.empty_like(fmap1), torch.empty_like(fmap2)
-        lay = block.layout
+        lay = block.grad_layout
         with torch.cuda.device(fmap1.device):
             nbytes = lib.rc_build_bwd_work_bytes(lay, block.in_dtype)
             if nbytes < 0:
@@ -105,9 +105,9 @@ class _LookupFn(torch.autograd.Function):
         dev = coords.device
         with torch.cuda.device(dev):
             if block.grad_volume is None:
-                block.grad_volume = torch.zeros(block.layout.total, dtype=torch.float32, device=dev)
+                block.grad_volume = torch.zeros(block.grad_layout.total, dtype=torch.float32, device=dev)
             check(lib.rc_lookup_bwd(coords.data_ptr(), coords.shape[1], grad_out.data_ptr(),
-                                    block.grad_volume.data_ptr(), block.layout, block.radius,
+                                    block.grad_volume.data_ptr(), block.grad_layout, block.radius,
                                     block.coord_mode, _stream(dev)), "rc_lookup_bwd")
         return torch.zeros(1, dtype=torch.float32, device=dev), None, None
 
@@ -136,8 +136,10 @@ class CorrBlock1DHip:
         if coord_mode is None:
             coord_mode = "gridsample" if fmap1.dtype == torch.float32 else "exact"
         self.coord_mode = COORD_MODES[coord_mode]
-        self.layout = Layout()
-        check(lib.rc_pyramid_layout(B, H, W1, W2, num_levels, self.layout), "rc_pyramid_layout")
+        self.layout = Layout()          # of the volume
+        self.grad_layout = Layout()     # of the float gradient pyramid
+        check(lib.rc_pyramid_layout(B, H, W1, W2, num_levels, self.vol_dtype, self.layout), "rc_pyramid_layout")
+        check(lib.rc_pyramid_layout(B, H, W1, W2, num_levels, _lib.RC_F32, self.grad_layout), "rc_pyramid_layout")
         self.volume = None
         self.grad_volume = None
         fmap1, fmap2 = fmap1.contiguous(), fmap2.contiguous()
@@ -152,7 +154,7 @@ class CorrBlock1DHip:
         with torch.cuda.device(self.device):
             self.volume = torch.empty(self.layout.total, dtype=self.volume_torch_dtype, device=self.device)
             check(lib.rc_build_pyramid(fmap1.data_ptr(), fmap2.data_ptr(), self.volume.data_ptr(), self.layout,
-                                       self.D, self.in_dtype, self.vol_dtype, _stream(self.device)),
+                                       self.D, self.in_dtype, _stream(self.device)),
                   "rc_build_pyramid")
 
     def _lookup(self, coords):
@@ -160,7 +162,7 @@ class CorrBlock1DHip:
         with torch.cuda.device(self.device):
             out = torch.empty((self.B, self.num_levels * nt, self.H, self.W1), dtype=torch.float32,
                               device=self.device)
-            check(lib.rc_lookup_fwd(self.volume.data_ptr(), self.layout, self.vol_dtype, coords.data_ptr(),
+            check(lib.rc_lookup_fwd(self.volume.data_ptr(), self.layout, coords.data_ptr(),
                                     coords.shape[1], out.data_ptr(), self.radius, self.coord_mode,
                                     _stream(self.device)), "rc_lookup_fwd")
         return out
@@ -172,17 +174,18 @@ class CorrBlock1DHip:
         return self._lookup(coords)
 
     # -- test / debug helper: the pyramid in the reference's dense layout
-    def dense_level(self, i):
+    def dense_level(self, i, volume=None, layout=None):
         """Level i as a dense [B,H,W1,W2>>i] tensor (un-skews the private layout with torch
         indexing; for tests only)."""
-        lay = self.layout
-        Wi, pitch = lay.width[i], lay.pitch
-        n = self.B * self.H * Wi * pitch
-        lvl = self.volume[lay.offset[i]:lay.offset[i] + n].view(self.B, self.H, Wi, pitch)
+        lay = layout or self.layout
+        vol = self.volume if volume is None else volume
+        Wi, WiP, pitch, rb = lay.width[i], lay.widthp[i], lay.pitch, lay.rb
+        n = self.B * self.H * WiP * pitch
+        lvl = vol[lay.offset[i]:lay.offset[i] + n].view(self.B, self.H, WiP // rb, pitch, rb)
         w1 = torch.arange(self.W1, device=self.device).view(-1, 1)
         w2 = torch.arange(Wi, device=self.device).view(1, -1)
-        s = ((w1 >> i) - w2) % Wi
-        return lvl[:, :, s, w1.expand_as(s)]
+        s = (w2 - (w1 >> i) - _lib.RC_SKEW) % WiP
+        return lvl[:, :, s // rb, w1.expand_as(s), s % rb]
 
 
 class AltCorrBlock1DHip:

@@ -10,8 +10,10 @@
 // are K-major; the f1 tile stays in registers for the whole sweep.  MFMA rows are w2 and MFMA
 // columns are w1, so a lane ends up with 4 consecutive w2 of one pixel: levels 1 and 2 of the
 // pyramid are in-register means, level 3 needs one cross-lane exchange.  All levels are
-// scattered into LDS rings indexed by the skew row u = (w1 >> i) - w2_i and flushed as whole
-// 64-pixel skew rows (full 128/256-byte lines) once a row is complete.
+// scattered into LDS rings indexed by the unwrapped skew row u = w2_i - (w1 >> i) - 17, stored
+// like the pyramid itself ([row block][pixel][rows of the block]); once the rows of a block are
+// complete for all 64 pixels of the tile the block is flushed with 16-byte stores, 1 KiB
+// contiguous per wave.
 #include "rc_common.h"
 
 #include <math.h>
@@ -46,10 +48,10 @@ template <typename T, typename VT, int TN> struct build_cfg {
   static constexpr int KSTEP = IS16 ? 32 : 4;
   static constexpr int NKS = KMAX / KSTEP;        // k-steps: 8 (16-bit) or 64 (f32)
   static constexpr int AT = TN / 32;              // 16-row (w2) MFMA tiles per wave
-  static constexpr int PR = sizeof(VT) == 2 ? 72 : 68;  // ring row pitch (elements)
+  static constexpr int RB = 16 / (int)sizeof(VT);  // skew rows per 16-byte block of the pyramid
   static constexpr int RING_ROWS = 128 + 64 + 32 + 16;
   static constexpr int LDSF_BYTES = KMAX * PF * ESZ;
-  static constexpr int RING_BYTES = RING_ROWS * PR * (int)sizeof(VT);
+  static constexpr int RING_BYTES = RING_ROWS * TM * (int)sizeof(VT);
   static constexpr int LDS_BYTES = LDSF_BYTES + RING_BYTES;
 };
 
@@ -174,33 +176,29 @@ __global__ __launch_bounds__(BT) void build_kernel(const T* __restrict__ f1, con
   const int n_chunks = (W2 + TN - 1) / TN;
   const int64_t rowblk = (int64_t)row;
 
-  // flush `count` skew rows of level i starting at u = ulo from the ring to global memory
-  auto flush = [&](int i, int ulo, int count) {
-    const int Wi = lay.width[i];
-    const int rmask = (128 >> i) - 1;
-    VT* lvl = vol + lay.offset[i] + (rowblk * Wi) * lay.pitch + c0;
-    const VT* rg = ring + ring_row0(i) * C::PR;
-    for (int it = threadIdx.x; it < count * 8; it += BT) {
-      const int rr = it >> 3, seg = it & 7;
-      const int u = ulo + rr;
-      const int dlo = ((c0 + seg * 8) >> i) - u, dhi = ((c0 + seg * 8 + 7) >> i) - u;
-      if (dhi < 0 || dlo >= Wi) continue;  // nothing of this segment exists
-      const int s = rc_pmod(u, Wi);
-      const VT* src = rg + (u & rmask) * C::PR + seg * 8;
-      VT* dst = lvl + (int64_t)s * lay.pitch + seg * 8;
-      if (dlo >= 0 && dhi < Wi) {
-        if constexpr (sizeof(VT) == 2) {
-          *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
-        } else {
-          reinterpret_cast<uint4*>(dst)[0] = reinterpret_cast<const uint4*>(src)[0];
-          reinterpret_cast<uint4*>(dst)[1] = reinterpret_cast<const uint4*>(src)[1];
-        }
+  // ring cell of unwrapped skew row u (level i), tile column w1l
+  auto ring_at = [&](int i, int u, int w1l) -> VT* {
+    const int rs = u & ((128 >> i) - 1);
+    return ring + ((ring_row0(i) + (rs & ~(C::RB - 1))) * TM + w1l * C::RB + (rs & (C::RB - 1)));
+  };
+
+  // flush `nblk` row blocks of level i starting at skew row ulo (a multiple of RB) to global memory
+  auto flush = [&](int i, int ulo, int nblk) {
+    const int Wi = lay.width[i], WiP = lay.widthp[i];
+    VT* lvl = vol + lay.offset[i] + (rowblk * (WiP / C::RB)) * lay.pitch * C::RB;
+    for (int it = threadIdx.x; it < nblk * TM; it += BT) {
+      const int blk = it >> 6, w1l = it & 63;
+      const int u0 = ulo + blk * C::RB;
+      const int w20 = u0 + ((c0 + w1l) >> i) + RC_SKEW;  // w2 of the block's first row for this pixel
+      if (w20 + C::RB - 1 < 0 || w20 >= Wi) continue;     // no cell of this block exists
+      const VT* src = ring_at(i, u0, w1l);
+      VT* dst = lvl + ((int64_t)(rc_pmod(u0, WiP) / C::RB) * lay.pitch + c0 + w1l) * C::RB;
+      if (w20 >= 0 && w20 + C::RB - 1 < Wi) {
+        *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
       } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int d = ((c0 + seg * 8 + e) >> i) - u;
-          if (d >= 0 && d < Wi) dst[e] = src[e];
-        }
+        for (int e = 0; e < C::RB; ++e)
+          if ((unsigned)(w20 + e) < (unsigned)Wi) dst[e] = src[e];
       }
     }
   };
@@ -257,24 +255,21 @@ __global__ __launch_bounds__(BT) void build_kernel(const T* __restrict__ f1, con
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           v0[r] = rc_round_as<VT>(acc[at][bt][r] * scale);
-          ring[((w1 - (w2b + r)) & 127) * C::PR + w1l] = rc_from_float<VT>(v0[r]);
+          *ring_at(0, w2b + r - w1 - RC_SKEW, w1l) = rc_from_float<VT>(v0[r]);
         }
         if (L > 1) {
           const float p10 = rc_round_as<VT>(0.5f * (v0[0] + v0[1]));
           const float p11 = rc_round_as<VT>(0.5f * (v0[2] + v0[3]));
-          const int u1 = (w1 >> 1) - (w2b >> 1);
-          VT* r1 = ring + ring_row0(1) * C::PR + w1l;
-          r1[(u1 & 63) * C::PR] = rc_from_float<VT>(p10);
-          r1[((u1 - 1) & 63) * C::PR] = rc_from_float<VT>(p11);
+          const int u1 = (w2b >> 1) - (w1 >> 1) - RC_SKEW;
+          *ring_at(1, u1, w1l) = rc_from_float<VT>(p10);
+          *ring_at(1, u1 + 1, w1l) = rc_from_float<VT>(p11);
           if (L > 2) {
             const float p2 = rc_round_as<VT>(0.5f * (p10 + p11));
-            const int u2 = (w1 >> 2) - (w2b >> 2);
-            ring[(ring_row0(2) + (u2 & 31)) * C::PR + w1l] = rc_from_float<VT>(p2);
+            *ring_at(2, (w2b >> 2) - (w1 >> 2) - RC_SKEW, w1l) = rc_from_float<VT>(p2);
             if (L > 3) {
               const float other = __shfl_xor(p2, 16);
               const float p3 = rc_round_as<VT>(0.5f * (p2 + other));
-              const int u3 = (w1 >> 3) - (w2b >> 3);
-              if ((g & 1) == 0) ring[(ring_row0(3) + (u3 & 15)) * C::PR + w1l] = rc_from_float<VT>(p3);
+              if ((g & 1) == 0) *ring_at(3, (w2b >> 3) - (w1 >> 3) - RC_SKEW, w1l) = rc_from_float<VT>(p3);
             }
           }
         }
@@ -282,17 +277,17 @@ __global__ __launch_bounds__(BT) void build_kernel(const T* __restrict__ f1, con
     }
     __syncthreads();
 
-    // ---- flush the skew rows completed by this chunk
+    // ---- flush the row blocks completed by this chunk (they start on a block boundary)
     for (int i = 0; i < L; ++i) {
       const int Mi = TM >> i, TNi = TN >> i;
-      flush(i, (c0 >> i) + Mi - (n0 >> i) - TNi, TNi);
+      flush(i, (n0 >> i) - (c0 >> i) - Mi - (RC_SKEW - 1), TNi / C::RB);
     }
   }
-  // rows that only partly exist (they wrap around modulo the level width)
+  // rows that never complete inside the tile (their other part belongs to the wrapped range)
   const int n0l = (n_chunks - 1) * TN;
   for (int i = 0; i < L; ++i) {
     const int Mi = TM >> i, TNi = TN >> i;
-    flush(i, (c0 >> i) - (n0l >> i) - TNi + 1, Mi - 1);
+    flush(i, (n0l >> i) + TNi - (c0 >> i) - Mi - (RC_SKEW - 1), (Mi + C::RB - 1) / C::RB);
   }
 }
 
@@ -301,38 +296,38 @@ __global__ __launch_bounds__(BT) void build_kernel(const T* __restrict__ f1, con
 template <typename T, typename VT>
 __global__ void naive_corr_kernel(const T* __restrict__ f1, const T* __restrict__ f2, VT* __restrict__ vol,
                                   rc_dev_layout lay, int D, float scale, int64_t total) {
+  constexpr int RB = 16 / (int)sizeof(VT);
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
   const int W1 = lay.W1, W2 = lay.W2;
   const int w1 = (int)(idx % W1);
   const int64_t t = idx / W1;
-  const int s = (int)(t % W2);
+  const int w2 = (int)(t % W2);
   const int64_t bh = t / W2;
   const int b = (int)(bh / lay.H), h = (int)(bh % lay.H);
-  const int w2 = rc_pmod(w1 - s, W2);
   const T* p1 = f1 + ((int64_t)b * D * lay.H + h) * W1 + w1;
   const T* p2 = f2 + ((int64_t)b * D * lay.H + h) * W2 + w2;
   float acc = 0.f;
   for (int k = 0; k < D; ++k)
     acc = fmaf(rc_to_float(p1[(int64_t)k * lay.H * W1]), rc_to_float(p2[(int64_t)k * lay.H * W2]), acc);
-  vol[lay.offset[0] + (bh * W2 + s) * lay.pitch + w1] = rc_from_float<VT>(acc * scale);
+  vol[rc_cell<RB>(lay, 0, bh, rc_pmod(w2 - w1 - RC_SKEW, lay.widthp[0]), w1)] = rc_from_float<VT>(acc * scale);
 }
 
 template <typename VT>
 __global__ void naive_pool_kernel(VT* __restrict__ vol, rc_dev_layout lay, int level, int64_t total) {
+  constexpr int RB = 16 / (int)sizeof(VT);
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
-  const int W1 = lay.W1, Wi = lay.width[level], Wp = lay.width[level - 1];
+  const int W1 = lay.W1, Wi = lay.width[level];
   const int w1 = (int)(idx % W1);
   const int64_t t = idx / W1;
-  const int s = (int)(t % Wi);
+  const int w2 = (int)(t % Wi);
   const int64_t bh = t / Wi;
-  const int w2 = rc_pmod((w1 >> level) - s, Wi);
-  const int qp = w1 >> (level - 1);
-  const VT* src = vol + lay.offset[level - 1] + (bh * Wp) * lay.pitch + w1;
-  const float a = rc_to_float(src[(int64_t)rc_pmod(qp - 2 * w2, Wp) * lay.pitch]);
-  const float bb = rc_to_float(src[(int64_t)rc_pmod(qp - 2 * w2 - 1, Wp) * lay.pitch]);
-  vol[lay.offset[level] + (bh * Wi + s) * lay.pitch + w1] = rc_from_float<VT>(0.5f * (a + bb));
+  const int qp = w1 >> (level - 1), WpP = lay.widthp[level - 1];
+  const float a = rc_to_float(vol[rc_cell<RB>(lay, level - 1, bh, rc_pmod(2 * w2 - qp - RC_SKEW, WpP), w1)]);
+  const float bb = rc_to_float(vol[rc_cell<RB>(lay, level - 1, bh, rc_pmod(2 * w2 + 1 - qp - RC_SKEW, WpP), w1)]);
+  vol[rc_cell<RB>(lay, level, bh, rc_pmod(w2 - (w1 >> level) - RC_SKEW, lay.widthp[level]), w1)] =
+      rc_from_float<VT>(0.5f * (a + bb));
 }
 
 template <typename T, typename VT>
@@ -387,15 +382,17 @@ int launch_build(const void* f1, const void* f2, void* vol, const rc_layout* lay
 }  // namespace
 
 static int build_dispatch(const void* f1, const void* f2, void* vol, const rc_layout* lay, int64_t D,
-                          int in_dtype, int vol_dtype, void* stream, bool force_naive) {
+                          int in_dtype, void* stream, bool force_naive) {
   RC_REQUIRE(f1 && f2 && vol && lay, RC_EINVAL, "null pointer argument");
   int rc = rc_validate_layout(lay);
   if (rc) return rc;
   RC_REQUIRE(D >= 1 && D < (1 << 20), RC_EINVAL, "bad feature depth D=%lld", (long long)D);
+  RC_REQUIRE((uintptr_t)vol % 16 == 0, RC_EINVAL, "pyramid pointer must be 16-byte aligned");
   const float scale = (float)(1.0 / sqrt((double)D));
   hipStream_t st = (hipStream_t)stream;
   const bool naive = force_naive || D > KMAX;
   const int iD = (int)D;
+  const int vol_dtype = lay->dtype;
 #define RC_BUILD_CASE(IN, VOL, T, VT, TN)                                            \
   if (in_dtype == IN && vol_dtype == VOL)                                            \
     return naive ? launch_naive<T, VT>(f1, f2, vol, lay, iD, scale, st)              \
@@ -406,17 +403,17 @@ static int build_dispatch(const void* f1, const void* f2, void* vol, const rc_la
   RC_BUILD_CASE(RC_F16, RC_F32, rc_half, float, 64)
   RC_BUILD_CASE(RC_BF16, RC_F32, rc_bf16, float, 64)
 #undef RC_BUILD_CASE
-  rc_set_error("unsupported (in_dtype=%d, vol_dtype=%d) combination", in_dtype, vol_dtype);
+  rc_set_error("unsupported (in_dtype=%d, pyramid dtype=%d) combination", in_dtype, vol_dtype);
   return RC_EUNSUPPORTED;
 }
 
 extern "C" int rc_build_pyramid(const void* f1, const void* f2, void* vol, const rc_layout* lay, int64_t D,
-                                int in_dtype, int vol_dtype, void* stream) {
-  return build_dispatch(f1, f2, vol, lay, D, in_dtype, vol_dtype, stream, false);
+                                int in_dtype, void* stream) {
+  return build_dispatch(f1, f2, vol, lay, D, in_dtype, stream, false);
 }
 
 // Diagnostic twin of rc_build_pyramid that always takes the one-thread-per-element kernels.
 extern "C" int rc_build_pyramid_naive(const void* f1, const void* f2, void* vol, const rc_layout* lay,
-                                      int64_t D, int in_dtype, int vol_dtype, void* stream) {
-  return build_dispatch(f1, f2, vol, lay, D, in_dtype, vol_dtype, stream, true);
+                                      int64_t D, int in_dtype, void* stream) {
+  return build_dispatch(f1, f2, vol, lay, D, in_dtype, stream, true);
 }

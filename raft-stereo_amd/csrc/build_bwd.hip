@@ -2,7 +2,7 @@
 //
 // Autograd of core/corr.py:119-125 (avg_pool2d chain) and :154-156 (einsum, / sqrt(D)).
 // Two steps on one stream:
-//   1. unskew_fold: reads every skew row once (coalesced), folds levels 1..L-1 into level 0
+//   1. unskew_fold: reads every 16-byte row block once (coalesced), folds levels 1..L-1 into level 0
 //      (each pooled cell spreads 2^-i of its gradient over its 2^i children), scales by
 //      1/sqrt(D), and writes the dense dC[b,h,w1,w2] and its transpose dCt[b,h,w2,w1] in the
 //      compute type, zero padded to a multiple of 32 along the contraction axis.
@@ -33,6 +33,7 @@ __global__ __launch_bounds__(256) void unskew_fold_kernel(const float* __restric
   const int c0 = blockIdx.x * UT, n0 = blockIdx.y * UT;
   const int64_t bh = blockIdx.z;
   const int W1 = lay.W1, W2 = lay.W2;
+  // (the gradient pyramid is float: 4 skew rows per 16-byte block)
   const int col = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int w1 = c0 + col;
 
@@ -41,19 +42,27 @@ __global__ __launch_bounds__(256) void unskew_fold_kernel(const float* __restric
 
   float wgt = scale;
   for (int i = 0; i < lay.L; ++i) {
-    const int Wi = lay.width[i];
+    const int Wi = lay.width[i], WiP = lay.widthp[i];
     const int q = w1 >> i;
-    const int nlo = n0 >> i, nhi = (n0 + UT - 1) >> i;      // pooled columns of this tile
-    const int ulo = (c0 >> i) - nhi;                         // lowest skew row touching the tile
-    const int nrows = ((c0 + UT - 1) >> i) - nlo - ulo + 1;
-    const float* lvl = gvol + lay.offset[i] + (bh * Wi) * lay.pitch;
-    for (int rr = rg; rr < nrows; rr += 4) {
-      const int u = ulo + rr;
-      const int w2i = q - u;
-      if (w1 < W1 && w2i >= nlo && w2i <= nhi && w2i < Wi) {
-        const float v = lvl[(int64_t)rc_pmod(u, Wi) * lay.pitch + w1] * wgt;
-        const int base = (w2i << i) - n0;
-        for (int e = 0; e < (1 << i); ++e) tile[col][base + e] += v;
+    const int nlo = n0 >> i, nhi = min((n0 + UT - 1) >> i, Wi - 1);   // pooled columns of this tile
+    // unwrapped skew rows u = w2 - q - 17 touching the tile, rounded down to a block of 4 rows
+    int ub0 = nlo - ((c0 + UT - 1) >> i) - RC_SKEW;
+    ub0 -= rc_pmod(ub0, 4);
+    const int uhi = nhi - (c0 >> i) - RC_SKEW;
+    const float* lvl = gvol + lay.offset[i] + (bh * (WiP / 4)) * lay.pitch * 4;
+    for (int u0 = ub0 + 4 * rg; u0 <= uhi; u0 += 16) {
+      const int w20 = u0 + q + RC_SKEW;
+      if (w1 < W1 && w20 + 3 >= nlo && w20 <= nhi) {
+        const float4 v4 = *reinterpret_cast<const float4*>(lvl + ((int64_t)(rc_pmod(u0, WiP) / 4) * lay.pitch + w1) * 4);
+        const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int w2i = w20 + r;
+          if (w2i >= nlo && w2i <= nhi) {
+            const int base = (w2i << i) - n0;
+            for (int e = 0; e < (1 << i); ++e) tile[col][base + e] += v[r] * wgt;
+          }
+        }
       }
     }
     wgt *= 0.5f;
@@ -233,6 +242,7 @@ extern "C" int rc_build_bwd(const float* grad_vol, const rc_layout* lay, const v
   RC_REQUIRE(grad_vol && lay && f1 && f2 && df1 && df2 && work, RC_EINVAL, "null pointer argument");
   int rc = rc_validate_layout(lay);
   if (rc) return rc;
+  RC_REQUIRE(lay->dtype == RC_F32, RC_EINVAL, "the gradient pyramid must use an RC_F32 layout");
   RC_REQUIRE(D >= 1 && D < (1 << 20), RC_EINVAL, "bad feature depth D=%lld", (long long)D);
   RC_REQUIRE((uintptr_t)work % 16 == 0, RC_EINVAL, "work buffer must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;

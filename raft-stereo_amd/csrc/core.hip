@@ -25,12 +25,14 @@ extern "C" int rc_version(void) { return RC_VERSION; }
 
 extern "C" const char* rc_last_error_string(void) { return g_err; }
 
-extern "C" int rc_pyramid_layout(int64_t B, int64_t H, int64_t W1, int64_t W2, int L, rc_layout* out) {
+extern "C" int rc_pyramid_layout(int64_t B, int64_t H, int64_t W1, int64_t W2, int L, int dtype,
+                                 rc_layout* out) {
   RC_REQUIRE(out != nullptr, RC_EINVAL, "rc_pyramid_layout: null output");
   RC_REQUIRE(B > 0 && H > 0 && W1 > 0 && W2 > 0, RC_EINVAL,
              "rc_pyramid_layout: non-positive size B=%lld H=%lld W1=%lld W2=%lld", (long long)B, (long long)H,
              (long long)W1, (long long)W2);
   RC_REQUIRE(L >= 1 && L <= RC_MAX_LEVELS, RC_EUNSUPPORTED, "num_levels %d outside 1..%d", L, RC_MAX_LEVELS);
+  RC_REQUIRE(dtype == RC_F32 || dtype == RC_F16 || dtype == RC_BF16, RC_EUNSUPPORTED, "unknown dtype %d", dtype);
   RC_REQUIRE((W2 >> (L - 1)) >= 1, RC_EINVAL, "W2=%lld is too small for %d levels (needs W2 >= %d)",
              (long long)W2, L, 1 << (L - 1));
   RC_REQUIRE(W1 < (1 << 24) && W2 < (1 << 24) && B * H < (1ll << 31), RC_EINVAL, "sizes exceed index range");
@@ -41,11 +43,14 @@ extern "C" int rc_pyramid_layout(int64_t B, int64_t H, int64_t W1, int64_t W2, i
   out->W2 = W2;
   out->L = L;
   out->pitch = (int32_t)((W1 + 63) / 64 * 64);
+  out->rb = dtype == RC_F32 ? 4 : 8;
+  out->dtype = dtype;
   int64_t off = 0;
   for (int i = 0; i < L; ++i) {
     out->width[i] = (int32_t)(W2 >> i);
+    out->widthp[i] = (out->width[i] + 7) / 8 * 8;
     out->offset[i] = off;
-    off += B * H * (int64_t)out->width[i] * out->pitch;
+    off += B * H * (int64_t)out->widthp[i] * out->pitch;
   }
   out->total = off;
   return RC_OK;
@@ -53,10 +58,8 @@ extern "C" int rc_pyramid_layout(int64_t B, int64_t H, int64_t W1, int64_t W2, i
 
 int rc_validate_layout(const rc_layout* lay) {
   rc_layout ref;
-  int rc = rc_pyramid_layout(lay->B, lay->H, lay->W1, lay->W2, lay->L, &ref);
+  int rc = rc_pyramid_layout(lay->B, lay->H, lay->W1, lay->W2, lay->L, lay->dtype, &ref);
   if (rc) return rc;
-  bool same = ref.pitch == lay->pitch && ref.total == lay->total;
-  for (int i = 0; i < lay->L; ++i) same = same && ref.width[i] == lay->width[i] && ref.offset[i] == lay->offset[i];
-  RC_REQUIRE(same, RC_EINVAL, "rc_layout was not produced by rc_pyramid_layout");
+  RC_REQUIRE(memcmp(&ref, lay, sizeof(ref)) == 0, RC_EINVAL, "rc_layout was not produced by rc_pyramid_layout");
   return RC_OK;
 }

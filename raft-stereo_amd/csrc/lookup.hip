@@ -1,38 +1,94 @@
-// Per-iteration correlation lookup, forward and adjoint, over the skewed pyramid.
+// Per-iteration correlation lookup, forward and adjoint, over the blocked-skew pyramid.
 //
 // Replaces core/corr.py:127-146 (reg), core/corr.py:44-51 + sampler/sampler_kernel.cu:19-105
 // (reg_cuda) of the reference.  One launch covers all levels.  A wave owns 64 consecutive
-// pixels of one image row; for a fixed tap those pixels read one or two skew rows of the
-// level at consecutive addresses (rc_layout), so the gather coalesces into full lines
-// whenever the disparity is locally smooth.  Outputs are written per channel plane, 256 B
-// per wave store.
+// pixels of one image row, one pixel per lane.  In the rc_layout a pixel's 2r+2 taps of a
+// level are consecutive skew rows of its own column, stored as aligned 16-byte blocks; the
+// lane loads the 2-3 (f16/bf16) or 3-4 (f32) blocks that cover its window with 16-byte loads
+// and shifts the taps into place in registers.  Pixels with similar disparity use the same row
+// blocks, so each load instruction of the wave reads one contiguous 1 KiB run.  Outputs are
+// written per channel plane, 256 B per wave store.
 #include "rc_common.h"
 
 namespace {
 
 constexpr int LK_THREADS = 256;  // 4 waves, each its own 64-pixel chunk
 
-template <typename VT> __device__ __forceinline__ float ld_vol(const VT* p) { return rc_to_float(*p); }
+template <typename VT> struct vt_info {
+  static constexpr int RB = 16 / (int)sizeof(VT);
+};
+
+__device__ __forceinline__ float half_bits_to_float(uint32_t h, rc_half) {
+  return (float)__builtin_bit_cast(rc_half, (uint16_t)h);
+}
+__device__ __forceinline__ float half_bits_to_float(uint32_t h, rc_bf16) { return __uint_as_float(h << 16); }
+
+// v[j] = column[s0 + j], j = 0..NT, for a window that does not wrap (s0 + NT < widthp).
+// `col` points at row block 0 of this pixel's column; consecutive blocks are `bstride` elements apart.
+template <typename VT, int NT>
+__device__ __forceinline__ void fetch_window(const VT* __restrict__ col, int64_t bstride, int s0, float (&v)[NT + 1]) {
+  constexpr int RB = vt_info<VT>::RB;
+  constexpr int NBLK = (RB + NT + RB - 1) / RB;  // blocks that can be touched
+  constexpr int ND = NBLK * 4;
+  const int blk0 = s0 / RB, o = s0 - blk0 * RB;
+  uint32_t d[ND];
+  const uint4* p = reinterpret_cast<const uint4*>(col + (int64_t)blk0 * bstride);
+  const int64_t bs16 = bstride * (int64_t)sizeof(VT) / 16;
+#pragma unroll
+  for (int k = 0; k < NBLK; ++k) {
+    uint4 q = make_uint4(0, 0, 0, 0);
+    if (k * RB <= o + NT) q = p[k * bs16];
+    d[4 * k + 0] = q.x;
+    d[4 * k + 1] = q.y;
+    d[4 * k + 2] = q.z;
+    d[4 * k + 3] = q.w;
+  }
+  const int sh = (sizeof(VT) == 4) ? o : (o >> 1);  // shift in dwords, 0..3
+#pragma unroll
+  for (int k = 0; k + 2 < ND; ++k) d[k] = (sh & 2) ? d[k + 2] : d[k];
+#pragma unroll
+  for (int k = 0; k + 3 < ND; ++k) d[k] = (sh & 1) ? d[k + 1] : d[k];
+  if constexpr (sizeof(VT) == 4) {
+#pragma unroll
+    for (int j = 0; j <= NT; ++j) v[j] = __uint_as_float(d[j]);
+  } else {
+    const uint32_t bsh = (o & 1) * 2;
+#pragma unroll
+    for (int k = 0; 2 * k <= NT; ++k) {
+      const uint32_t t = __builtin_amdgcn_alignbyte(d[k + 1], d[k], bsh);
+      v[2 * k] = half_bits_to_float(t & 0xffffu, VT());
+      if (2 * k + 1 <= NT) v[2 * k + 1] = half_bits_to_float(t >> 16, VT());
+    }
+  }
+}
 
 // One level of the forward lookup for one pixel.  R is the compile-time radius.
 template <typename VT, int R, int MODE>
-__device__ __forceinline__ void lookup_level(const VT* __restrict__ lvl_row0, int pitch, int Wi,
-                                             int qm, float xi, float* __restrict__ outp,
-                                             int64_t out_cstride) {
+__device__ __forceinline__ void lookup_level(const VT* __restrict__ col, int64_t bstride, int Wi, int WiP, int qm,
+                                             float xi, float* __restrict__ outp, int64_t out_cstride) {
   constexpr int NT = 2 * R + 1;
+  constexpr int RB = vt_info<VT>::RB;
   const float xf = floorf(xi);
   const float a = xi - xf;
   const int base = rc_safe_int(xf) - R;
 
   float v[NT + 1];
+  const bool any_ok = (base + NT >= 0) && (base < Wi);
+  const int s0 = any_ok ? rc_pmod(base - qm - RC_SKEW, WiP) : 0;
+  if (!any_ok) {
 #pragma unroll
-  for (int j = 0; j <= NT; ++j) {
-    const int w2 = base + j;
-    const bool ok = (unsigned)w2 < (unsigned)Wi;
-    int s = qm - w2;
-    s += (s < 0) ? Wi : 0;
-    v[j] = ok ? ld_vol(lvl_row0 + (int64_t)s * pitch) : 0.f;
+    for (int j = 0; j <= NT; ++j) v[j] = 0.f;
+  } else if (s0 + NT < WiP) {
+    fetch_window<VT, NT>(col, bstride, s0, v);
+  } else {  // the window wraps around the modulus (disparity of about -12..-21 level pixels)
+#pragma unroll
+    for (int j = 0; j <= NT; ++j) {
+      const int s = (s0 + j) % WiP;  // levels narrower than the window wrap more than once
+      v[j] = rc_to_float(col[(int64_t)(s / RB) * bstride + (s % RB)]);
+    }
   }
+#pragma unroll
+  for (int j = 0; j <= NT; ++j) v[j] = ((unsigned)(base + j) < (unsigned)Wi) ? v[j] : 0.f;
 
   if (MODE == RC_COORD_EXACT) {
     const float b = 1.0f - a;
@@ -55,11 +111,9 @@ __device__ __forceinline__ void lookup_level(const VT* __restrict__ lvl_row0, in
         float va = v[k], vb = v[k + 1];
         if (i0[k] != base + k) {
           const int wa = i0[k], wb = i0[k] + 1;
-          int sa = qm - wa, sb = qm - wb;
-          sa += (sa < 0) ? Wi : 0;
-          sb += (sb < 0) ? Wi : 0;
-          va = ((unsigned)wa < (unsigned)Wi) ? ld_vol(lvl_row0 + (int64_t)sa * pitch) : 0.f;
-          vb = ((unsigned)wb < (unsigned)Wi) ? ld_vol(lvl_row0 + (int64_t)sb * pitch) : 0.f;
+          const int sa = rc_pmod(wa - qm - RC_SKEW, WiP), sb = rc_pmod(wb - qm - RC_SKEW, WiP);
+          va = ((unsigned)wa < (unsigned)Wi) ? rc_to_float(col[(int64_t)(sa / RB) * bstride + (sa % RB)]) : 0.f;
+          vb = ((unsigned)wb < (unsigned)Wi) ? rc_to_float(col[(int64_t)(sb / RB) * bstride + (sb % RB)]) : 0.f;
         }
         outp[k * out_cstride] = va * w0[k] + vb * w1[k];
       }
@@ -78,6 +132,7 @@ __global__ __launch_bounds__(LK_THREADS) void lookup_fwd_kernel(const VT* __rest
                                                                 float* __restrict__ out,
                                                                 int chunks_per_row, int n_items) {
   constexpr int NT = 2 * R + 1;
+  constexpr int RB = vt_info<VT>::RB;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int item = blockIdx.x * (LK_THREADS / 64) + wave;  // (row, 64-pixel chunk)
   if (item >= n_items) return;
@@ -86,22 +141,23 @@ __global__ __launch_bounds__(LK_THREADS) void lookup_fwd_kernel(const VT* __rest
   if (w1 >= lay.W1) return;
   const int b = bh / lay.H, h = bh - b * lay.H;
   const int64_t HW = (int64_t)lay.H * lay.W1;
+  const int64_t bstride = (int64_t)lay.pitch * RB;
 
   const float x = coords[((int64_t)b * coords_channels) * HW + (int64_t)h * lay.W1 + w1];
   float* outp = out + ((int64_t)b * lay.L * NT) * HW + (int64_t)h * lay.W1 + w1;
 
   float inv = 1.0f;
   for (int i = 0; i < lay.L; ++i) {
-    const int Wi = lay.width[i];
-    const int qm = (w1 >> i) % Wi;
-    const VT* row0 = vol + lay.offset[i] + ((int64_t)bh * Wi) * lay.pitch + w1;
-    lookup_level<VT, R, MODE>(row0, lay.pitch, Wi, qm, x * inv, outp + (int64_t)i * NT * HW, HW);
+    const int Wi = lay.width[i], WiP = lay.widthp[i];
+    const int qm = (w1 >> i) % WiP;
+    const VT* col = vol + lay.offset[i] + ((int64_t)bh * (WiP / RB) * lay.pitch + w1) * RB;
+    lookup_level<VT, R, MODE>(col, bstride, Wi, WiP, qm, x * inv, outp + (int64_t)i * NT * HW, HW);
     inv *= 0.5f;
   }
 }
 
-// Adjoint: grad_vol (float pyramid) += scatter of grad_out.  The pixel owns column w1 of every
-// skew row, so plain read-modify-write is race free.
+// Adjoint: grad_vol (float pyramid, RB = 4) += scatter of grad_out.  The pixel owns its column
+// of every level, so plain read-modify-write of its 16-byte blocks is race free.
 template <int R, int MODE>
 __global__ __launch_bounds__(LK_THREADS) void lookup_bwd_kernel(const float* __restrict__ coords,
                                                                 int coords_channels,
@@ -110,6 +166,9 @@ __global__ __launch_bounds__(LK_THREADS) void lookup_bwd_kernel(const float* __r
                                                                 rc_dev_layout lay, int chunks_per_row,
                                                                 int n_items) {
   constexpr int NT = 2 * R + 1;
+  constexpr int RB = 4;
+  constexpr int NBLK = (RB + NT + RB - 1) / RB;
+  constexpr int ND = NBLK * 4;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int item = blockIdx.x * (LK_THREADS / 64) + wave;
   if (item >= n_items) return;
@@ -118,15 +177,16 @@ __global__ __launch_bounds__(LK_THREADS) void lookup_bwd_kernel(const float* __r
   if (w1 >= lay.W1) return;
   const int b = bh / lay.H, h = bh - b * lay.H;
   const int64_t HW = (int64_t)lay.H * lay.W1;
+  const int64_t bstride = (int64_t)lay.pitch * RB;
 
   const float x = coords[((int64_t)b * coords_channels) * HW + (int64_t)h * lay.W1 + w1];
   const float* gp = gout + ((int64_t)b * lay.L * NT) * HW + (int64_t)h * lay.W1 + w1;
 
   float inv = 1.0f;
   for (int i = 0; i < lay.L; ++i) {
-    const int Wi = lay.width[i];
-    const int qm = (w1 >> i) % Wi;
-    float* row0 = gvol + lay.offset[i] + ((int64_t)bh * Wi) * lay.pitch + w1;
+    const int Wi = lay.width[i], WiP = lay.widthp[i];
+    const int qm = (w1 >> i) % WiP;
+    float* col = gvol + lay.offset[i] + ((int64_t)bh * (WiP / RB) * lay.pitch + w1) * RB;
     const float xi = x * inv;
     inv *= 0.5f;
     const float xf = floorf(xi);
@@ -137,9 +197,9 @@ __global__ __launch_bounds__(LK_THREADS) void lookup_bwd_kernel(const float* __r
 #pragma unroll
     for (int k = 0; k < NT; ++k) g[k] = gp[((int64_t)i * NT + k) * HW];
 
-    float t[NT + 1];
+    float t[ND];
 #pragma unroll
-    for (int j = 0; j <= NT; ++j) t[j] = 0.f;
+    for (int j = 0; j < ND; ++j) t[j] = 0.f;
 
     if (MODE == RC_COORD_EXACT) {
       const float bw = 1.0f - a;
@@ -162,25 +222,52 @@ __global__ __launch_bounds__(LK_THREADS) void lookup_bwd_kernel(const float* __r
           // rare: this tap landed on a neighbouring integer; update its two cells directly
           const int wa = i0, wb = i0 + 1;
           if ((unsigned)wa < (unsigned)Wi) {
-            int s = qm - wa;
-            s += (s < 0) ? Wi : 0;
-            row0[(int64_t)s * lay.pitch] += g[k] * w0;
+            const int s = rc_pmod(wa - qm - RC_SKEW, WiP);
+            col[(int64_t)(s / RB) * bstride + (s % RB)] += g[k] * w0;
           }
           if ((unsigned)wb < (unsigned)Wi) {
-            int s = qm - wb;
-            s += (s < 0) ? Wi : 0;
-            row0[(int64_t)s * lay.pitch] += g[k] * w1w;
+            const int s = rc_pmod(wb - qm - RC_SKEW, WiP);
+            col[(int64_t)(s / RB) * bstride + (s % RB)] += g[k] * w1w;
           }
         }
       }
     }
 #pragma unroll
-    for (int j = 0; j <= NT; ++j) {
-      const int w2 = base + j;
-      if ((unsigned)w2 < (unsigned)Wi) {
-        int s = qm - w2;
-        s += (s < 0) ? Wi : 0;
-        row0[(int64_t)s * lay.pitch] += t[j];
+    for (int j = 0; j <= NT; ++j) t[j] = ((unsigned)(base + j) < (unsigned)Wi) ? t[j] : 0.f;
+
+    const bool any_ok = (base + NT >= 0) && (base < Wi);
+    if (!any_ok) continue;
+    const int s0 = rc_pmod(base - qm - RC_SKEW, WiP);
+    if (s0 + NT < WiP) {
+      const int blk0 = s0 / RB, o = s0 - blk0 * RB;
+      // move tap j to slot o + j
+#pragma unroll
+      for (int m = ND - 1; m >= 1; --m) t[m] = (o & 1) ? t[m - 1] : t[m];
+      t[0] = (o & 1) ? 0.f : t[0];
+#pragma unroll
+      for (int m = ND - 1; m >= 2; --m) t[m] = (o & 2) ? t[m - 2] : t[m];
+      t[1] = (o & 2) ? 0.f : t[1];
+      t[0] = (o & 2) ? 0.f : t[0];
+      float4* p = reinterpret_cast<float4*>(col + (int64_t)blk0 * bstride);
+      const int64_t bs16 = bstride / 4;
+#pragma unroll
+      for (int k = 0; k < NBLK; ++k) {
+        if (k * RB <= o + NT) {
+          float4 q = p[k * bs16];
+          q.x += t[4 * k + 0];
+          q.y += t[4 * k + 1];
+          q.z += t[4 * k + 2];
+          q.w += t[4 * k + 3];
+          p[k * bs16] = q;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j <= NT; ++j) {
+        if ((unsigned)(base + j) < (unsigned)Wi) {
+          const int s = (s0 + j) % WiP;
+          col[(int64_t)(s / RB) * bstride + (s % RB)] += t[j];
+        }
       }
     }
   }
@@ -248,32 +335,34 @@ int check_common(const rc_layout* lay, const void* a, const void* b, const void*
                "grid_sample coordinates need every level at least 2 wide (W2=%lld, L=%d)",
                (long long)lay->W2, lay->L);
   RC_REQUIRE((int64_t)lay->B * lay->H * ((lay->W1 + 63) / 64) < (1ll << 31), RC_EINVAL, "too many pixels");
+  RC_REQUIRE((uintptr_t)a % 16 == 0, RC_EINVAL, "pyramid pointer must be 16-byte aligned");
   return RC_OK;
 }
 
 }  // namespace
 
-extern "C" int rc_lookup_fwd(const void* vol, const rc_layout* lay, int vol_dtype, const float* coords,
-                             int coords_channels, float* out, int radius, int coord_mode, void* stream) {
+extern "C" int rc_lookup_fwd(const void* vol, const rc_layout* lay, const float* coords, int coords_channels,
+                             float* out, int radius, int coord_mode, void* stream) {
   int rc = check_common(lay, vol, coords, out, coords_channels, radius, coord_mode);
   if (rc) return rc;
   const rc_dev_layout d = rc_to_dev(lay);
   hipStream_t st = (hipStream_t)stream;
-  switch (vol_dtype) {
+  switch (lay->dtype) {
     case RC_F32: return dispatch_fwd_radius<float>(vol, d, coords, coords_channels, out, radius, coord_mode, st);
     case RC_F16: return dispatch_fwd_radius<rc_half>(vol, d, coords, coords_channels, out, radius, coord_mode, st);
     case RC_BF16: return dispatch_fwd_radius<rc_bf16>(vol, d, coords, coords_channels, out, radius, coord_mode, st);
   }
-  rc_set_error("unknown vol_dtype %d", vol_dtype);
+  rc_set_error("unknown pyramid dtype %d", lay->dtype);
   return RC_EUNSUPPORTED;
 }
 
 extern "C" int rc_lookup_bwd(const float* coords, int coords_channels, const float* grad_out,
-                             float* grad_vol, const rc_layout* lay, int radius, int coord_mode,
+                             float* grad_vol, const rc_layout* glay, int radius, int coord_mode,
                              void* stream) {
-  int rc = check_common(lay, coords, grad_out, grad_vol, coords_channels, radius, coord_mode);
+  int rc = check_common(glay, grad_vol, coords, grad_out, coords_channels, radius, coord_mode);
   if (rc) return rc;
-  const rc_dev_layout d = rc_to_dev(lay);
+  RC_REQUIRE(glay->dtype == RC_F32, RC_EINVAL, "the gradient pyramid must use an RC_F32 layout");
+  const rc_dev_layout d = rc_to_dev(glay);
   hipStream_t st = (hipStream_t)stream;
   switch (radius) {
     case 1: return launch_bwd<1>(coords, coords_channels, grad_out, grad_vol, d, coord_mode, st);

@@ -43,12 +43,15 @@ template <typename T> __device__ __forceinline__ float rc_round_as(float v) {
 }
 
 // ---------------------------------------------------------------- pyramid layout on device
+constexpr int RC_SKEW = 17;  // s = (w2 - (w1 >> i) - RC_SKEW) mod widthp  (see rc_layout)
+
 struct rc_dev_layout {
   int32_t L;
   int32_t pitch;
   int32_t H, W1, W2;
   int32_t B;
   int32_t width[RC_MAX_LEVELS];
+  int32_t widthp[RC_MAX_LEVELS];
   int64_t offset[RC_MAX_LEVELS];
 };
 
@@ -62,6 +65,7 @@ static inline rc_dev_layout rc_to_dev(const rc_layout* lay) {
   d.B = (int32_t)lay->B;
   for (int i = 0; i < RC_MAX_LEVELS; ++i) {
     d.width[i] = lay->width[i];
+    d.widthp[i] = lay->widthp[i];
     d.offset[i] = lay->offset[i];
   }
   return d;
@@ -74,6 +78,13 @@ int rc_validate_layout(const rc_layout* lay);
 __device__ __forceinline__ int rc_pmod(int a, int m) {
   int r = a % m;
   return r < 0 ? r + m : r;
+}
+
+// Element offset of skew row s, pixel w1 inside the level-`i` slab of image row `bh`
+// (RB = rows per 16-byte block = 16 / sizeof(element)).
+template <int RB>
+__device__ __forceinline__ int64_t rc_cell(const rc_dev_layout& lay, int i, int64_t bh, int s, int w1) {
+  return lay.offset[i] + ((bh * (lay.widthp[i] / RB) + s / RB) * lay.pitch + w1) * RB + (s % RB);
 }
 
 // float -> int that maps nan / huge values to a far-out-of-range index (all taps zero)

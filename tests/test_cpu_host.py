@@ -27,41 +27,50 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_layout_matches_documented_formula():
-    from raft_stereo_amd._lib import lib, Layout
+    from raft_stereo_amd._lib import lib, Layout, RC_F16, RC_F32
     lay = Layout()
-    assert lib.rc_pyramid_layout(8, 96, 312, 312, 4, lay) == 0
-    assert lay.pitch == 320 and list(lay.width) == [312, 156, 78, 39]
+    assert lib.rc_pyramid_layout(8, 96, 312, 312, 4, RC_F16, lay) == 0
+    assert lay.pitch == 320 and lay.rb == 8 and lay.dtype == RC_F16
+    assert list(lay.width) == [312, 156, 78, 39] and list(lay.widthp) == [312, 160, 80, 40]
     off = 0
     for i in range(4):
         assert lay.offset[i] == off
-        off += 8 * 96 * lay.width[i] * lay.pitch
+        off += 8 * 96 * lay.widthp[i] * lay.pitch
     assert lay.total == off
-    assert lib.rc_pyramid_layout(1, 1, 16, 4, 4, lay) != 0          # W2 too small for 4 levels
+    assert lib.rc_pyramid_layout(8, 96, 312, 312, 4, RC_F32, lay) == 0 and lay.rb == 4
+    assert lib.rc_pyramid_layout(1, 1, 16, 4, 4, RC_F32, lay) != 0          # W2 too small for 4 levels
     assert b"too small" in lib.rc_last_error_string()
-    assert lib.rc_pyramid_layout(1, 1, 16, 64, 5, lay) != 0         # more levels than compiled
-    assert lib.rc_pyramid_layout(0, 1, 16, 64, 4, lay) != 0
+    assert lib.rc_pyramid_layout(1, 1, 16, 64, 5, RC_F32, lay) != 0         # more levels than compiled
+    assert lib.rc_pyramid_layout(0, 1, 16, 64, 4, RC_F32, lay) != 0
+    assert lib.rc_pyramid_layout(1, 1, 16, 64, 4, 7, lay) != 0              # unknown dtype
 
 
 def test_null_and_bad_arguments_are_rejected_without_a_gpu():
-    from raft_stereo_amd._lib import lib, Layout
+    from raft_stereo_amd._lib import lib, Layout, RC_F32
     lay = Layout()
-    lib.rc_pyramid_layout(1, 2, 64, 64, 4, lay)
-    assert lib.rc_lookup_fwd(None, lay, 0, None, 2, None, 4, 0, None) == -1
-    assert lib.rc_build_pyramid(None, None, None, lay, 256, 0, 0, None) == -1
+    lib.rc_pyramid_layout(1, 2, 64, 64, 4, RC_F32, lay)
+    assert lib.rc_lookup_fwd(None, lay, None, 2, None, 4, 0, None) == -1
+    assert lib.rc_build_pyramid(None, None, None, lay, 256, 0, None) == -1
     lay.pitch = 100                                                  # forged layout
-    assert lib.rc_lookup_fwd(1, lay, 0, 1, 2, 1, 4, 0, None) == -1
+    assert lib.rc_lookup_fwd(16, lay, 16, 2, 16, 4, 0, None) == -1
     assert b"rc_pyramid_layout" in lib.rc_last_error_string()
 
 
 def test_skew_index_is_a_bijection():
-    """Every (w1, w2) of a level maps to its own (skew row, column) cell."""
-    for W1, W2, i in [(40, 45, 0), (40, 45, 2), (72, 200, 3), (200, 45, 1), (33, 33, 1)]:
+    """Every (w1, w2) of a level maps to its own cell of the blocked-skew layout, and for a
+    fixed pixel consecutive w2 are consecutive skew rows (modulo the padded width)."""
+    from raft_stereo_amd._lib import RC_SKEW
+    for W1, W2, i, rb in [(40, 45, 0, 8), (40, 45, 2, 4), (72, 200, 3, 8), (200, 45, 1, 4), (33, 33, 1, 8)]:
         Wi = W2 >> i
+        WiP = (Wi + 7) // 8 * 8
+        pitch = (W1 + 63) // 64 * 64
         w1 = np.arange(W1)[:, None]
         w2 = np.arange(Wi)[None, :]
-        s = ((w1 >> i) - w2) % Wi
-        cells = set(zip(s.ravel().tolist(), np.broadcast_to(w1, s.shape).ravel().tolist()))
-        assert len(cells) == W1 * Wi
+        s = (w2 - (w1 >> i) - RC_SKEW) % WiP
+        cell = ((s // rb) * pitch + w1) * rb + s % rb
+        assert len(set(cell.ravel().tolist())) == W1 * Wi
+        assert cell.max() < WiP * pitch
+        assert np.all((s[:, 1:] - s[:, :-1]) % WiP == 1)
 
 
 def test_dispatch_and_shards():
