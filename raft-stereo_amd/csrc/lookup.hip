@@ -23,108 +23,58 @@ __device__ __forceinline__ float half_bits_to_float(uint32_t h, rc_half) {
 }
 __device__ __forceinline__ float half_bits_to_float(uint32_t h, rc_bf16) { return __uint_as_float(h << 16); }
 
-// v[j] = column[s0 + j], j = 0..NT, for a window that does not wrap (s0 + NT < widthp).
-// `col` points at row block 0 of this pixel's column; consecutive blocks are `bstride` elements apart.
-template <typename VT, int NT>
-__device__ __forceinline__ void fetch_window(const VT* __restrict__ col, int64_t bstride, int s0, float (&v)[NT + 1]) {
-  constexpr int RB = vt_info<VT>::RB;
-  constexpr int NBLK = (RB + NT + RB - 1) / RB;  // blocks that can be touched
-  constexpr int ND = NBLK * 4;
-  const int blk0 = s0 / RB, o = s0 - blk0 * RB;
+// A pixel's tap window of one level: the 16-byte blocks that cover skew rows s0 .. s0+NT of its
+// column, loaded first (all levels in flight together), decoded later.
+template <typename VT, int NT> struct tap_window {
+  static constexpr int RB = vt_info<VT>::RB;
+  static constexpr int NBLK = (RB + NT + RB - 1) / RB;  // blocks a window can touch
+  static constexpr int ND = NBLK * 4;
   uint32_t d[ND];
-  const uint4* p = reinterpret_cast<const uint4*>(col + (int64_t)blk0 * bstride);
-  const int64_t bs16 = bstride * (int64_t)sizeof(VT) / 16;
+  int o;  // row of the first tap inside the first block
+
+  // `col` points at row block 0 of this pixel's column; blocks are `bs16` 16-byte units apart.
+  // `fast` = the window is in range and does not wrap (s0 + NT < widthp).
+  __device__ __forceinline__ void load(const VT* __restrict__ col, int64_t bs16, int s0, bool fast) {
+    const int blk0 = s0 / RB;
+    o = s0 - blk0 * RB;
+    const uint4* p = reinterpret_cast<const uint4*>(col) + (int64_t)blk0 * bs16;
 #pragma unroll
-  for (int k = 0; k < NBLK; ++k) {
-    uint4 q = make_uint4(0, 0, 0, 0);
-    if (k * RB <= o + NT) q = p[k * bs16];
-    d[4 * k + 0] = q.x;
-    d[4 * k + 1] = q.y;
-    d[4 * k + 2] = q.z;
-    d[4 * k + 3] = q.w;
-  }
-  const int sh = (sizeof(VT) == 4) ? o : (o >> 1);  // shift in dwords, 0..3
-#pragma unroll
-  for (int k = 0; k + 2 < ND; ++k) d[k] = (sh & 2) ? d[k + 2] : d[k];
-#pragma unroll
-  for (int k = 0; k + 3 < ND; ++k) d[k] = (sh & 1) ? d[k + 1] : d[k];
-  if constexpr (sizeof(VT) == 4) {
-#pragma unroll
-    for (int j = 0; j <= NT; ++j) v[j] = __uint_as_float(d[j]);
-  } else {
-    const uint32_t bsh = (o & 1) * 2;
-#pragma unroll
-    for (int k = 0; 2 * k <= NT; ++k) {
-      const uint32_t t = __builtin_amdgcn_alignbyte(d[k + 1], d[k], bsh);
-      v[2 * k] = half_bits_to_float(t & 0xffffu, VT());
-      if (2 * k + 1 <= NT) v[2 * k + 1] = half_bits_to_float(t >> 16, VT());
+    for (int k = 0; k < NBLK; ++k) {
+      uint4 q = make_uint4(0, 0, 0, 0);
+      if (fast && k * RB <= o + NT) q = p[k * bs16];
+      d[4 * k + 0] = q.x;
+      d[4 * k + 1] = q.y;
+      d[4 * k + 2] = q.z;
+      d[4 * k + 3] = q.w;
     }
   }
-}
 
-// One level of the forward lookup for one pixel.  R is the compile-time radius.
-template <typename VT, int R, int MODE>
-__device__ __forceinline__ void lookup_level(const VT* __restrict__ col, int64_t bstride, int Wi, int WiP, int qm,
-                                             float xi, float* __restrict__ outp, int64_t out_cstride) {
-  constexpr int NT = 2 * R + 1;
-  constexpr int RB = vt_info<VT>::RB;
-  const float xf = floorf(xi);
-  const float a = xi - xf;
-  const int base = rc_safe_int(xf) - R;
-
-  float v[NT + 1];
-  const bool any_ok = (base + NT >= 0) && (base < Wi);
-  const int s0 = any_ok ? rc_pmod(base - qm - RC_SKEW, WiP) : 0;
-  if (!any_ok) {
+  // v[j] = column[s0 + j]: shift the window down by `o` rows with two select stages (+ one
+  // byte-align for 16-bit elements)
+  __device__ __forceinline__ void decode(float (&v)[NT + 1]) {
+    const int sh = (sizeof(VT) == 4) ? o : (o >> 1);  // shift in dwords, 0..3
 #pragma unroll
-    for (int j = 0; j <= NT; ++j) v[j] = 0.f;
-  } else if (s0 + NT < WiP) {
-    fetch_window<VT, NT>(col, bstride, s0, v);
-  } else {  // the window wraps around the modulus (disparity of about -12..-21 level pixels)
+    for (int k = 0; k + 2 < ND; ++k) d[k] = (sh & 2) ? d[k + 2] : d[k];
 #pragma unroll
-    for (int j = 0; j <= NT; ++j) {
-      const int s = (s0 + j) % WiP;  // levels narrower than the window wrap more than once
-      v[j] = rc_to_float(col[(int64_t)(s / RB) * bstride + (s % RB)]);
-    }
-  }
+    for (int k = 0; k + 3 < ND; ++k) d[k] = (sh & 1) ? d[k + 1] : d[k];
+    if constexpr (sizeof(VT) == 4) {
 #pragma unroll
-  for (int j = 0; j <= NT; ++j) v[j] = ((unsigned)(base + j) < (unsigned)Wi) ? v[j] : 0.f;
-
-  if (MODE == RC_COORD_EXACT) {
-    const float b = 1.0f - a;
-#pragma unroll
-    for (int k = 0; k < NT; ++k) outp[k * out_cstride] = v[k] * b + v[k + 1] * a;
-  } else {
-    const float wm1 = (float)(Wi - 1);
-    int i0[NT];
-    float w0[NT], w1[NT];
-    bool odd = false;
-#pragma unroll
-    for (int k = 0; k < NT; ++k) {
-      rc_gridsample_coords(xi, k - R, wm1, &i0[k], &w0[k], &w1[k]);
-      odd |= (i0[k] != base + k);
-    }
-    if (__builtin_expect(__any(odd), 0)) {
-      // the fp32 round trip moved some tap across an integer: fetch those taps directly
-#pragma unroll
-      for (int k = 0; k < NT; ++k) {
-        float va = v[k], vb = v[k + 1];
-        if (i0[k] != base + k) {
-          const int wa = i0[k], wb = i0[k] + 1;
-          const int sa = rc_pmod(wa - qm - RC_SKEW, WiP), sb = rc_pmod(wb - qm - RC_SKEW, WiP);
-          va = ((unsigned)wa < (unsigned)Wi) ? rc_to_float(col[(int64_t)(sa / RB) * bstride + (sa % RB)]) : 0.f;
-          vb = ((unsigned)wb < (unsigned)Wi) ? rc_to_float(col[(int64_t)(sb / RB) * bstride + (sb % RB)]) : 0.f;
-        }
-        outp[k * out_cstride] = va * w0[k] + vb * w1[k];
-      }
+      for (int j = 0; j <= NT; ++j) v[j] = __uint_as_float(d[j]);
     } else {
+      const uint32_t bsh = (o & 1) * 2;
 #pragma unroll
-      for (int k = 0; k < NT; ++k) outp[k * out_cstride] = v[k] * w0[k] + v[k + 1] * w1[k];
+      for (int k = 0; 2 * k <= NT; ++k) {
+        const uint32_t t = __builtin_amdgcn_alignbyte(d[k + 1], d[k], bsh);
+        v[2 * k] = half_bits_to_float(t & 0xffffu, VT());
+        if (2 * k + 1 <= NT) v[2 * k + 1] = half_bits_to_float(t >> 16, VT());
+      }
     }
   }
-}
+};
 
-template <typename VT, int R, int MODE>
+// LV = compile-time level count (fully unrolled, every level's loads issued before the first
+// use) or 0 for a run-time count.
+template <typename VT, int R, int MODE, int LV>
 __global__ __launch_bounds__(LK_THREADS) void lookup_fwd_kernel(const VT* __restrict__ vol,
                                                                 rc_dev_layout lay,
                                                                 const float* __restrict__ coords,
@@ -133,6 +83,7 @@ __global__ __launch_bounds__(LK_THREADS) void lookup_fwd_kernel(const VT* __rest
                                                                 int chunks_per_row, int n_items) {
   constexpr int NT = 2 * R + 1;
   constexpr int RB = vt_info<VT>::RB;
+  constexpr int LMAX = LV ? LV : RC_MAX_LEVELS;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int item = blockIdx.x * (LK_THREADS / 64) + wave;  // (row, 64-pixel chunk)
   if (item >= n_items) return;
@@ -141,18 +92,92 @@ __global__ __launch_bounds__(LK_THREADS) void lookup_fwd_kernel(const VT* __rest
   if (w1 >= lay.W1) return;
   const int b = bh / lay.H, h = bh - b * lay.H;
   const int64_t HW = (int64_t)lay.H * lay.W1;
+  const int64_t bs16 = (int64_t)lay.pitch * RB * (int64_t)sizeof(VT) / 16;
   const int64_t bstride = (int64_t)lay.pitch * RB;
+  const int L = LV ? LV : lay.L;
 
   const float x = coords[((int64_t)b * coords_channels) * HW + (int64_t)h * lay.W1 + w1];
-  float* outp = out + ((int64_t)b * lay.L * NT) * HW + (int64_t)h * lay.W1 + w1;
+  float* outp = out + ((int64_t)b * L * NT) * HW + (int64_t)h * lay.W1 + w1;
 
-  float inv = 1.0f;
-  for (int i = 0; i < lay.L; ++i) {
-    const int Wi = lay.width[i], WiP = lay.widthp[i];
-    const int qm = (w1 >> i) % WiP;
-    const VT* col = vol + lay.offset[i] + ((int64_t)bh * (WiP / RB) * lay.pitch + w1) * RB;
-    lookup_level<VT, R, MODE>(col, bstride, Wi, WiP, qm, x * inv, outp + (int64_t)i * NT * HW, HW);
-    inv *= 0.5f;
+  tap_window<VT, NT> win[LMAX];
+  int base[LMAX], s0[LMAX];
+  float frac[LMAX];
+  bool slow[LMAX];
+
+  // ---- phase 1: addresses and loads of every level
+#pragma unroll
+  for (int i = 0; i < LMAX; ++i) {
+    if (i < L) {
+      const int Wi = lay.width[i], WiP = lay.widthp[i];
+      const float xi = x * (1.0f / (float)(1 << i));
+      const float xf = floorf(xi);
+      frac[i] = xi - xf;
+      base[i] = rc_safe_int(xf) - R;
+      const bool any_ok = (base[i] + NT >= 0) && (base[i] < Wi);
+      s0[i] = any_ok ? rc_pmod(base[i] - (w1 >> i) - RC_SKEW, WiP) : 0;
+      const bool fast = any_ok && (s0[i] + NT < WiP);
+      slow[i] = any_ok && !fast;  // the window wraps around the modulus (disparity about -12..-21)
+      const VT* col = vol + lay.offset[i] + ((int64_t)bh * (WiP / RB) * lay.pitch + w1) * RB;
+      win[i].load(col, bs16, s0[i], fast);
+    }
+  }
+
+  // ---- phase 2: decode, interpolate, store
+#pragma unroll
+  for (int i = 0; i < LMAX; ++i) {
+    if (i < L) {
+      const int Wi = lay.width[i], WiP = lay.widthp[i];
+      const VT* col = vol + lay.offset[i] + ((int64_t)bh * (WiP / RB) * lay.pitch + w1) * RB;
+      float* op = outp + (int64_t)i * NT * HW;
+      float v[NT + 1];
+      win[i].decode(v);
+      if (__builtin_expect(__any(slow[i]), 0)) {
+        if (slow[i]) {
+#pragma unroll
+          for (int j = 0; j <= NT; ++j) {
+            const int s = (s0[i] + j) % WiP;  // levels narrower than the window wrap more than once
+            v[j] = rc_to_float(col[(int64_t)(s / RB) * bstride + (s % RB)]);
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j <= NT; ++j) v[j] = ((unsigned)(base[i] + j) < (unsigned)Wi) ? v[j] : 0.f;
+
+      if (MODE == RC_COORD_EXACT) {
+        const float a = frac[i], bw = 1.0f - a;
+#pragma unroll
+        for (int k = 0; k < NT; ++k) op[k * HW] = v[k] * bw + v[k + 1] * a;
+      } else {
+        const float xi = x * (1.0f / (float)(1 << i));
+        const float wm1 = (float)(Wi - 1);
+        const int qm = w1 >> i;
+        int i0[NT];
+        float w0[NT], w1w[NT];
+        bool odd = false;
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+          rc_gridsample_coords(xi, k - R, wm1, &i0[k], &w0[k], &w1w[k]);
+          odd |= (i0[k] != base[i] + k);
+        }
+        if (__builtin_expect(__any(odd), 0)) {
+          // the fp32 round trip moved some tap across an integer: fetch those taps directly
+#pragma unroll
+          for (int k = 0; k < NT; ++k) {
+            float va = v[k], vb = v[k + 1];
+            if (i0[k] != base[i] + k) {
+              const int wa = i0[k], wb = i0[k] + 1;
+              const int sa = rc_pmod(wa - qm - RC_SKEW, WiP), sb = rc_pmod(wb - qm - RC_SKEW, WiP);
+              va = ((unsigned)wa < (unsigned)Wi) ? rc_to_float(col[(int64_t)(sa / RB) * bstride + (sa % RB)]) : 0.f;
+              vb = ((unsigned)wb < (unsigned)Wi) ? rc_to_float(col[(int64_t)(sb / RB) * bstride + (sb % RB)]) : 0.f;
+            }
+            op[k * HW] = va * w0[k] + vb * w1w[k];
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < NT; ++k) op[k * HW] = v[k] * w0[k] + v[k + 1] * w1w[k];
+        }
+      }
+    }
   }
 }
 
@@ -280,12 +305,15 @@ int launch_fwd(const void* vol, const rc_dev_layout& d, const float* coords, int
   const int64_t items64 = (int64_t)d.B * d.H * chunks;
   const int n_items = (int)items64;
   const int blocks = (n_items + (LK_THREADS / 64) - 1) / (LK_THREADS / 64);
-  if (mode == RC_COORD_EXACT)
-    hipLaunchKernelGGL((lookup_fwd_kernel<VT, R, RC_COORD_EXACT>), dim3(blocks), dim3(LK_THREADS), 0, st,
-                       (const VT*)vol, d, coords, cc, out, chunks, n_items);
-  else
-    hipLaunchKernelGGL((lookup_fwd_kernel<VT, R, RC_COORD_GRIDSAMPLE>), dim3(blocks), dim3(LK_THREADS), 0,
-                       st, (const VT*)vol, d, coords, cc, out, chunks, n_items);
+#define RC_LAUNCH(MODE, LV)                                                                                \
+  hipLaunchKernelGGL((lookup_fwd_kernel<VT, R, MODE, LV>), dim3(blocks), dim3(LK_THREADS), 0, st, (const VT*)vol, \
+                     d, coords, cc, out, chunks, n_items)
+  if (R == 4 && d.L == 4) {  // the model's configuration: fully unrolled
+    if (mode == RC_COORD_EXACT) RC_LAUNCH(RC_COORD_EXACT, 4); else RC_LAUNCH(RC_COORD_GRIDSAMPLE, 4);
+  } else {
+    if (mode == RC_COORD_EXACT) RC_LAUNCH(RC_COORD_EXACT, 0); else RC_LAUNCH(RC_COORD_GRIDSAMPLE, 0);
+  }
+#undef RC_LAUNCH
   return rc_check_launch("rc_lookup_fwd");
 }
 
