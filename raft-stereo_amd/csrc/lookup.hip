@@ -16,6 +16,7 @@ constexpr int LK_THREADS = 256;  // 4 waves, each its own 64-pixel chunk
 
 template <typename VT> struct vt_info {
   static constexpr int RB = 16 / (int)sizeof(VT);
+  static constexpr int LG = sizeof(VT) == 4 ? 2 : 3;  // log2(RB)
 };
 
 __device__ __forceinline__ float half_bits_to_float(uint32_t h, rc_half) {
@@ -23,57 +24,53 @@ __device__ __forceinline__ float half_bits_to_float(uint32_t h, rc_half) {
 }
 __device__ __forceinline__ float half_bits_to_float(uint32_t h, rc_bf16) { return __uint_as_float(h << 16); }
 
-// A pixel's tap window of one level: the 16-byte blocks that cover skew rows s0 .. s0+NT of its
-// column, loaded first (all levels in flight together), decoded later.
-template <typename VT, int NT> struct tap_window {
-  static constexpr int RB = vt_info<VT>::RB;
-  static constexpr int NBLK = (RB + NT + RB - 1) / RB;  // blocks a window can touch
-  static constexpr int ND = NBLK * 4;
-  uint32_t d[ND];
-  int o;  // row of the first tap inside the first block
+// t mod m in [0, m) for |t| < 2^22 without an integer division (inv_m = 1.0f / m)
+__device__ __forceinline__ int fast_pmod(int t, int m, float inv_m) {
+  const int q = (int)floorf((float)t * inv_m);
+  int r = t - q * m;
+  r += (r < 0) ? m : 0;
+  r -= (r >= m) ? m : 0;
+  return r;
+}
 
-  // `col` points at row block 0 of this pixel's column; blocks are `bs16` 16-byte units apart.
-  // `fast` = the window is in range and does not wrap (s0 + NT < widthp).
-  __device__ __forceinline__ void load(const VT* __restrict__ col, int64_t bs16, int s0, bool fast) {
-    const int blk0 = s0 / RB;
-    o = s0 - blk0 * RB;
-    const uint4* p = reinterpret_cast<const uint4*>(col) + (int64_t)blk0 * bs16;
+// v[j] = element (o + j) of the window held in the dwords d[0..ND): shift down by `o` elements
+// with two select stages (+ one byte-align for 16-bit elements)
+template <typename VT, int NT, int ND>
+__device__ __forceinline__ void decode_window(uint32_t (&d)[ND], int o, float (&v)[NT + 1]) {
+  const int sh = (sizeof(VT) == 4) ? o : (o >> 1);  // shift in dwords, 0..3
+  // (both operands are read into temporaries first: a select between array ELEMENTS would be
+  // turned into a dynamically indexed, scratch-backed array by the compiler)
+  const bool s2 = (sh & 2) != 0, s1 = (sh & 1) != 0;
 #pragma unroll
-    for (int k = 0; k < NBLK; ++k) {
-      uint4 q = make_uint4(0, 0, 0, 0);
-      if (fast && k * RB <= o + NT) q = p[k * bs16];
-      d[4 * k + 0] = q.x;
-      d[4 * k + 1] = q.y;
-      d[4 * k + 2] = q.z;
-      d[4 * k + 3] = q.w;
+  for (int k = 0; k + 2 < ND; ++k) {
+    const uint32_t lo = d[k], hi = d[k + 2];
+    d[k] = s2 ? hi : lo;
+  }
+#pragma unroll
+  for (int k = 0; k + 3 < ND; ++k) {
+    const uint32_t lo = d[k], hi = d[k + 1];
+    d[k] = s1 ? hi : lo;
+  }
+  if constexpr (sizeof(VT) == 4) {
+#pragma unroll
+    for (int j = 0; j <= NT; ++j) v[j] = __uint_as_float(d[j]);
+  } else {
+    const uint32_t bsh = (o & 1) * 2;
+#pragma unroll
+    for (int k = 0; 2 * k <= NT; ++k) {
+      const uint32_t t = __builtin_amdgcn_alignbyte(d[k + 1], d[k], bsh);
+      v[2 * k] = half_bits_to_float(t & 0xffffu, VT());
+      if (2 * k + 1 <= NT) v[2 * k + 1] = half_bits_to_float(t >> 16, VT());
     }
   }
+}
 
-  // v[j] = column[s0 + j]: shift the window down by `o` rows with two select stages (+ one
-  // byte-align for 16-bit elements)
-  __device__ __forceinline__ void decode(float (&v)[NT + 1]) {
-    const int sh = (sizeof(VT) == 4) ? o : (o >> 1);  // shift in dwords, 0..3
-#pragma unroll
-    for (int k = 0; k + 2 < ND; ++k) d[k] = (sh & 2) ? d[k + 2] : d[k];
-#pragma unroll
-    for (int k = 0; k + 3 < ND; ++k) d[k] = (sh & 1) ? d[k + 1] : d[k];
-    if constexpr (sizeof(VT) == 4) {
-#pragma unroll
-      for (int j = 0; j <= NT; ++j) v[j] = __uint_as_float(d[j]);
-    } else {
-      const uint32_t bsh = (o & 1) * 2;
-#pragma unroll
-      for (int k = 0; 2 * k <= NT; ++k) {
-        const uint32_t t = __builtin_amdgcn_alignbyte(d[k + 1], d[k], bsh);
-        v[2 * k] = half_bits_to_float(t & 0xffffu, VT());
-        if (2 * k + 1 <= NT) v[2 * k + 1] = half_bits_to_float(t >> 16, VT());
-      }
-    }
-  }
-};
-
-// LV = compile-time level count (fully unrolled, every level's loads issued before the first
-// use) or 0 for a run-time count.
+// A wave owns 64 consecutive pixels of one image row.  Everything that does not depend on the
+// lane (row, chunk, level bases, output planes) is kept wave-uniform so that loads and stores use
+// scalar base + 32-bit lane offset addressing.  LV > 0 is a compile-time level count: the 16-byte
+// loads of all levels are issued back to back (no branch in between: lanes that do not need a
+// block re-read one they do need), then decoded, interpolated and stored.  LV == 0 takes the level
+// count from the layout and handles one level at a time.
 template <typename VT, int R, int MODE, int LV>
 __global__ __launch_bounds__(LK_THREADS) void lookup_fwd_kernel(const VT* __restrict__ vol,
                                                                 rc_dev_layout lay,
@@ -82,99 +79,124 @@ __global__ __launch_bounds__(LK_THREADS) void lookup_fwd_kernel(const VT* __rest
                                                                 float* __restrict__ out,
                                                                 int chunks_per_row, int n_items) {
   constexpr int NT = 2 * R + 1;
-  constexpr int RB = vt_info<VT>::RB;
-  constexpr int LMAX = LV ? LV : RC_MAX_LEVELS;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int item = blockIdx.x * (LK_THREADS / 64) + wave;  // (row, 64-pixel chunk)
+  constexpr int RB = vt_info<VT>::RB, LG = vt_info<VT>::LG;
+  constexpr int NBLK = (RB + NT + RB - 1) / RB;  // 16-byte blocks a window can touch
+  constexpr int ND = NBLK * 4;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int item = blockIdx.x * (LK_THREADS / 64) + wave;  // (row, 64-pixel chunk), wave-uniform
   if (item >= n_items) return;
   const int bh = item / chunks_per_row;
-  const int w1 = (item - bh * chunks_per_row) * 64 + lane;
+  const int c0 = (item - bh * chunks_per_row) * 64;
+  const int w1 = c0 + lane;
   if (w1 >= lay.W1) return;
   const int b = bh / lay.H, h = bh - b * lay.H;
   const int64_t HW = (int64_t)lay.H * lay.W1;
-  const int64_t bs16 = (int64_t)lay.pitch * RB * (int64_t)sizeof(VT) / 16;
-  const int64_t bstride = (int64_t)lay.pitch * RB;
+  constexpr int LB = LV ? LV : 1;  // levels in flight together
   const int L = LV ? LV : lay.L;
+  const uint32_t blk_bytes = (uint32_t)lay.pitch * 16u;  // distance between row blocks of a pixel
 
-  const float x = coords[((int64_t)b * coords_channels) * HW + (int64_t)h * lay.W1 + w1];
-  float* outp = out + ((int64_t)b * L * NT) * HW + (int64_t)h * lay.W1 + w1;
+  const float x = (coords + ((int64_t)b * coords_channels) * HW + (int64_t)h * lay.W1 + c0)[lane];
+  float* out_u = out + ((int64_t)b * L * NT) * HW + (int64_t)h * lay.W1 + c0;  // wave-uniform
 
-  tap_window<VT, NT> win[LMAX];
-  int base[LMAX], s0[LMAX];
-  float frac[LMAX];
-  bool slow[LMAX];
+  for (int i0 = 0; i0 < L; i0 += LB) {
+    uint32_t d[LB][ND];
+    int base[LB], s0[LB], o[LB];
+    float frac[LB];
+    bool slow[LB];
 
-  // ---- phase 1: addresses and loads of every level
+    // ---- phase 1: addresses and loads of LB levels
 #pragma unroll
-  for (int i = 0; i < LMAX; ++i) {
-    if (i < L) {
-      const int Wi = lay.width[i], WiP = lay.widthp[i];
-      const float xi = x * (1.0f / (float)(1 << i));
-      const float xf = floorf(xi);
-      frac[i] = xi - xf;
-      base[i] = rc_safe_int(xf) - R;
-      const bool any_ok = (base[i] + NT >= 0) && (base[i] < Wi);
-      s0[i] = any_ok ? rc_pmod(base[i] - (w1 >> i) - RC_SKEW, WiP) : 0;
-      const bool fast = any_ok && (s0[i] + NT < WiP);
-      slow[i] = any_ok && !fast;  // the window wraps around the modulus (disparity about -12..-21)
-      const VT* col = vol + lay.offset[i] + ((int64_t)bh * (WiP / RB) * lay.pitch + w1) * RB;
-      win[i].load(col, bs16, s0[i], fast);
-    }
-  }
-
-  // ---- phase 2: decode, interpolate, store
+    for (int j = 0; j < LB; ++j) {
+      const int i = i0 + j;
+      {
+        const int Wi = lay.width[i], WiP = lay.widthp[i];
+        const float xi = x * (1.0f / (float)(1 << i));
+        const float xf = floorf(xi);
+        frac[j] = xi - xf;
+        base[j] = rc_safe_int(xf) - R;
+        const bool any_ok = (base[j] + NT >= 0) && (base[j] < Wi);
+        const int t = any_ok ? base[j] - (w1 >> i) - RC_SKEW : 0;
+        s0[j] = fast_pmod(t, WiP, 1.0f / (float)WiP);
+        const bool fast = any_ok && (s0[j] + NT < WiP);
+        slow[j] = any_ok && !fast;  // the window wraps around the modulus (disparity about -12..-21)
+        const int s0c = fast ? s0[j] : 0;
+        o[j] = s0c & (RB - 1);
+        const int blk0 = s0c >> LG;
+        const int nb = fast ? ((o[j] + NT) >> LG) : 0;  // last block this lane needs
+        const char* lvl = reinterpret_cast<const char*>(vol + lay.offset[i]) +
+                          (int64_t)bh * (WiP >> LG) * blk_bytes;  // wave-uniform
+        const uint32_t voff = (uint32_t)blk0 * blk_bytes + (uint32_t)w1 * 16u;
 #pragma unroll
-  for (int i = 0; i < LMAX; ++i) {
-    if (i < L) {
-      const int Wi = lay.width[i], WiP = lay.widthp[i];
-      const VT* col = vol + lay.offset[i] + ((int64_t)bh * (WiP / RB) * lay.pitch + w1) * RB;
-      float* op = outp + (int64_t)i * NT * HW;
-      float v[NT + 1];
-      win[i].decode(v);
-      if (__builtin_expect(__any(slow[i]), 0)) {
-        if (slow[i]) {
-#pragma unroll
-          for (int j = 0; j <= NT; ++j) {
-            const int s = (s0[i] + j) % WiP;  // levels narrower than the window wrap more than once
-            v[j] = rc_to_float(col[(int64_t)(s / RB) * bstride + (s % RB)]);
-          }
+        for (int k = 0; k < NBLK; ++k) {
+          const uint32_t kk = (uint32_t)min(k, nb);
+          const uint4 q = *reinterpret_cast<const uint4*>(lvl + (voff + kk * blk_bytes));
+          d[j][4 * k + 0] = q.x;
+          d[j][4 * k + 1] = q.y;
+          d[j][4 * k + 2] = q.z;
+          d[j][4 * k + 3] = q.w;
         }
       }
-#pragma unroll
-      for (int j = 0; j <= NT; ++j) v[j] = ((unsigned)(base[i] + j) < (unsigned)Wi) ? v[j] : 0.f;
+    }
 
-      if (MODE == RC_COORD_EXACT) {
-        const float a = frac[i], bw = 1.0f - a;
+    // ---- phase 2: decode, interpolate, store
 #pragma unroll
-        for (int k = 0; k < NT; ++k) op[k * HW] = v[k] * bw + v[k + 1] * a;
-      } else {
-        const float xi = x * (1.0f / (float)(1 << i));
-        const float wm1 = (float)(Wi - 1);
-        const int qm = w1 >> i;
-        int i0[NT];
-        float w0[NT], w1w[NT];
-        bool odd = false;
+    for (int j = 0; j < LB; ++j) {
+      const int i = i0 + j;
+      {
+        const int Wi = lay.width[i], WiP = lay.widthp[i];
+        float* op = out_u + (int64_t)i * NT * HW;  // wave-uniform plane base
+        float v[NT + 1];
+        decode_window<VT, NT, ND>(d[j], o[j], v);
+        if (__builtin_expect(__any(slow[j]), 0)) {
+          if (slow[j]) {
+            const VT* col = vol + lay.offset[i] + ((int64_t)bh * (WiP >> LG) * lay.pitch + w1) * RB;
 #pragma unroll
-        for (int k = 0; k < NT; ++k) {
-          rc_gridsample_coords(xi, k - R, wm1, &i0[k], &w0[k], &w1w[k]);
-          odd |= (i0[k] != base[i] + k);
+            for (int m = 0; m <= NT; ++m) {
+              const int s = (s0[j] + m) % WiP;  // levels narrower than the window wrap more than once
+              v[m] = rc_to_float(col[(int64_t)(s >> LG) * lay.pitch * RB + (s & (RB - 1))]);
+            }
+          }
         }
-        if (__builtin_expect(__any(odd), 0)) {
-          // the fp32 round trip moved some tap across an integer: fetch those taps directly
+#pragma unroll
+        for (int m = 0; m <= NT; ++m) v[m] = ((unsigned)(base[j] + m) < (unsigned)Wi) ? v[m] : 0.f;
+
+        if (MODE == RC_COORD_EXACT) {
+          const float a = frac[j], bw = 1.0f - a;
+#pragma unroll
+          for (int k = 0; k < NT; ++k) (op + k * HW)[lane] = v[k] * bw + v[k + 1] * a;
+        } else {
+          const float xi = x * (1.0f / (float)(1 << i));
+          const float wm1 = (float)(Wi - 1);
+          const int qm = w1 >> i;
+          int i0k[NT];
+          float w0[NT], w1w[NT];
+          bool odd = false;
 #pragma unroll
           for (int k = 0; k < NT; ++k) {
-            float va = v[k], vb = v[k + 1];
-            if (i0[k] != base[i] + k) {
-              const int wa = i0[k], wb = i0[k] + 1;
-              const int sa = rc_pmod(wa - qm - RC_SKEW, WiP), sb = rc_pmod(wb - qm - RC_SKEW, WiP);
-              va = ((unsigned)wa < (unsigned)Wi) ? rc_to_float(col[(int64_t)(sa / RB) * bstride + (sa % RB)]) : 0.f;
-              vb = ((unsigned)wb < (unsigned)Wi) ? rc_to_float(col[(int64_t)(sb / RB) * bstride + (sb % RB)]) : 0.f;
-            }
-            op[k * HW] = va * w0[k] + vb * w1w[k];
+            rc_gridsample_coords(xi, k - R, wm1, &i0k[k], &w0[k], &w1w[k]);
+            odd |= (i0k[k] != base[j] + k);
           }
-        } else {
+          if (__builtin_expect(__any(odd), 0)) {
+            // the fp32 round trip moved some tap across an integer: fetch those taps directly
+            const VT* col = vol + lay.offset[i] + ((int64_t)bh * (WiP >> LG) * lay.pitch + w1) * RB;
 #pragma unroll
-          for (int k = 0; k < NT; ++k) op[k * HW] = v[k] * w0[k] + v[k + 1] * w1w[k];
+            for (int k = 0; k < NT; ++k) {
+              float va = v[k], vb = v[k + 1];
+              if (i0k[k] != base[j] + k) {
+                const int wa = i0k[k], wb = i0k[k] + 1;
+                const int sa = rc_pmod(wa - qm - RC_SKEW, WiP), sb = rc_pmod(wb - qm - RC_SKEW, WiP);
+                va = ((unsigned)wa < (unsigned)Wi)
+                         ? rc_to_float(col[(int64_t)(sa >> LG) * lay.pitch * RB + (sa & (RB - 1))]) : 0.f;
+                vb = ((unsigned)wb < (unsigned)Wi)
+                         ? rc_to_float(col[(int64_t)(sb >> LG) * lay.pitch * RB + (sb & (RB - 1))]) : 0.f;
+              }
+              (op + k * HW)[lane] = va * w0[k] + vb * w1w[k];
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < NT; ++k) (op + k * HW)[lane] = v[k] * w0[k] + v[k + 1] * w1w[k];
+          }
         }
       }
     }
@@ -308,7 +330,7 @@ int launch_fwd(const void* vol, const rc_dev_layout& d, const float* coords, int
 #define RC_LAUNCH(MODE, LV)                                                                                \
   hipLaunchKernelGGL((lookup_fwd_kernel<VT, R, MODE, LV>), dim3(blocks), dim3(LK_THREADS), 0, st, (const VT*)vol, \
                      d, coords, cc, out, chunks, n_items)
-  if (R == 4 && d.L == 4) {  // the model's configuration: fully unrolled
+  if (R == 4 && d.L == 4) {  // the model's configuration: all levels' loads in flight together
     if (mode == RC_COORD_EXACT) RC_LAUNCH(RC_COORD_EXACT, 4); else RC_LAUNCH(RC_COORD_GRIDSAMPLE, 4);
   } else {
     if (mode == RC_COORD_EXACT) RC_LAUNCH(RC_COORD_EXACT, 0); else RC_LAUNCH(RC_COORD_GRIDSAMPLE, 0);
@@ -363,6 +385,8 @@ int check_common(const rc_layout* lay, const void* a, const void* b, const void*
                "grid_sample coordinates need every level at least 2 wide (W2=%lld, L=%d)",
                (long long)lay->W2, lay->L);
   RC_REQUIRE((int64_t)lay->B * lay->H * ((lay->W1 + 63) / 64) < (1ll << 31), RC_EINVAL, "too many pixels");
+  RC_REQUIRE((int64_t)(lay->widthp[0] / lay->rb + 1) * lay->pitch * 16 < (1ll << 31), RC_EINVAL,
+             "one image row of the pyramid exceeds the 32-bit lane offset range");
   RC_REQUIRE((uintptr_t)a % 16 == 0, RC_EINVAL, "pyramid pointer must be 16-byte aligned");
   return RC_OK;
 }
