@@ -24,13 +24,25 @@ __device__ __forceinline__ float half_bits_to_float(uint32_t h, rc_half) {
 }
 __device__ __forceinline__ float half_bits_to_float(uint32_t h, rc_bf16) { return __uint_as_float(h << 16); }
 
-// t mod m in [0, m) for |t| < 2^22 without an integer division (inv_m = 1.0f / m)
-__device__ __forceinline__ int fast_pmod(int t, int m, float inv_m) {
-  const int q = (int)floorf((float)t * inv_m);
-  int r = t - q * m;
-  r += (r < 0) ? m : 0;
-  r -= (r >= m) ? m : 0;
-  return r;
+// (t mod m) in [0, m) for t + bias >= 0, bias a multiple of m (set_skew_bias): two conditional
+// subtractions when t + bias < 4 m (always, unless a level is only a few pixels wide)
+__device__ __forceinline__ int skew_pmod(int t_plus_bias, int m, int bias) {
+  uint32_t r = (uint32_t)t_plus_bias;
+  if (bias <= 3 * m) {  // wave-uniform
+    r = min(r, r - 2u * (uint32_t)m);
+    r = min(r, r - (uint32_t)m);
+    return (int)r;
+  }
+  return (int)(r % (uint32_t)m);
+}
+
+// An offset the compiler must keep in scalar registers (the value is wave-uniform by
+// construction), so that base + uniform(offset) stays a scalar address and the lane index goes
+// into the 32-bit vector offset of the memory instruction
+__device__ __forceinline__ int64_t uniform(int64_t v) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uint64_t)v);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+  return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
 // v[j] = element (o + j) of the window held in the dwords d[0..ND): shift down by `o` elements
@@ -96,14 +108,14 @@ __global__ __launch_bounds__(LK_THREADS) void lookup_fwd_kernel(const VT* __rest
   const int L = LV ? LV : lay.L;
   const uint32_t blk_bytes = (uint32_t)lay.pitch * 16u;  // distance between row blocks of a pixel
 
-  const float x = (coords + ((int64_t)b * coords_channels) * HW + (int64_t)h * lay.W1 + c0)[lane];
-  float* out_u = out + ((int64_t)b * L * NT) * HW + (int64_t)h * lay.W1 + c0;  // wave-uniform
+  const float x = (coords + uniform(((int64_t)b * coords_channels) * HW + (int64_t)h * lay.W1 + c0))[lane];
+  const int64_t out_u = ((int64_t)b * L * NT) * HW + (int64_t)h * lay.W1 + c0;  // wave-uniform
 
   for (int i0 = 0; i0 < L; i0 += LB) {
     uint32_t d[LB][ND];
     int base[LB], s0[LB], o[LB];
     float frac[LB];
-    bool slow[LB];
+    bool slow[LB], edge[LB];
 
     // ---- phase 1: addresses and loads of LB levels
 #pragma unroll
@@ -116,21 +128,23 @@ __global__ __launch_bounds__(LK_THREADS) void lookup_fwd_kernel(const VT* __rest
         frac[j] = xi - xf;
         base[j] = rc_safe_int(xf) - R;
         const bool any_ok = (base[j] + NT >= 0) && (base[j] < Wi);
-        const int t = any_ok ? base[j] - (w1 >> i) - RC_SKEW : 0;
-        s0[j] = fast_pmod(t, WiP, 1.0f / (float)WiP);
+        edge[j] = (base[j] < 0) || (base[j] + NT >= Wi);  // some tap is outside the image
+        const int bias = lay.bias[i];
+        const int t = (any_ok ? base[j] - (w1 >> i) - RC_SKEW : 0) + bias;
+        s0[j] = skew_pmod(t, WiP, bias);
         const bool fast = any_ok && (s0[j] + NT < WiP);
         slow[j] = any_ok && !fast;  // the window wraps around the modulus (disparity about -12..-21)
         const int s0c = fast ? s0[j] : 0;
         o[j] = s0c & (RB - 1);
         const int blk0 = s0c >> LG;
         const int nb = fast ? ((o[j] + NT) >> LG) : 0;  // last block this lane needs
-        const char* lvl = reinterpret_cast<const char*>(vol + lay.offset[i]) +
-                          (int64_t)bh * (WiP >> LG) * blk_bytes;  // wave-uniform
-        const uint32_t voff = (uint32_t)blk0 * blk_bytes + (uint32_t)w1 * 16u;
+        const char* lvl = reinterpret_cast<const char*>(vol) +
+                          uniform(lay.offset[i] * (int64_t)sizeof(VT) + (int64_t)bh * (WiP >> LG) * blk_bytes);
+        const uint32_t voff = __umul24((uint32_t)blk0, blk_bytes) + (uint32_t)w1 * 16u;
 #pragma unroll
         for (int k = 0; k < NBLK; ++k) {
           const uint32_t kk = (uint32_t)min(k, nb);
-          const uint4 q = *reinterpret_cast<const uint4*>(lvl + (voff + kk * blk_bytes));
+          const uint4 q = *reinterpret_cast<const uint4*>(lvl + (voff + __umul24(kk, blk_bytes)));
           d[j][4 * k + 0] = q.x;
           d[j][4 * k + 1] = q.y;
           d[j][4 * k + 2] = q.z;
@@ -145,7 +159,7 @@ __global__ __launch_bounds__(LK_THREADS) void lookup_fwd_kernel(const VT* __rest
       const int i = i0 + j;
       {
         const int Wi = lay.width[i], WiP = lay.widthp[i];
-        float* op = out_u + (int64_t)i * NT * HW;  // wave-uniform plane base
+        const int64_t op = out_u + (int64_t)i * NT * HW;  // wave-uniform plane base
         float v[NT + 1];
         decode_window<VT, NT, ND>(d[j], o[j], v);
         if (__builtin_expect(__any(slow[j]), 0)) {
@@ -158,13 +172,15 @@ __global__ __launch_bounds__(LK_THREADS) void lookup_fwd_kernel(const VT* __rest
             }
           }
         }
+        if (__any(edge[j])) {  // interior waves skip the zero padding
 #pragma unroll
-        for (int m = 0; m <= NT; ++m) v[m] = ((unsigned)(base[j] + m) < (unsigned)Wi) ? v[m] : 0.f;
+          for (int m = 0; m <= NT; ++m) v[m] = ((unsigned)(base[j] + m) < (unsigned)Wi) ? v[m] : 0.f;
+        }
 
         if (MODE == RC_COORD_EXACT) {
           const float a = frac[j], bw = 1.0f - a;
 #pragma unroll
-          for (int k = 0; k < NT; ++k) (op + k * HW)[lane] = v[k] * bw + v[k + 1] * a;
+          for (int k = 0; k < NT; ++k) (out + uniform(op + k * HW))[lane] = v[k] * bw + v[k + 1] * a;
         } else {
           const float xi = x * (1.0f / (float)(1 << i));
           const float wm1 = (float)(Wi - 1);
@@ -191,11 +207,11 @@ __global__ __launch_bounds__(LK_THREADS) void lookup_fwd_kernel(const VT* __rest
                 vb = ((unsigned)wb < (unsigned)Wi)
                          ? rc_to_float(col[(int64_t)(sb >> LG) * lay.pitch * RB + (sb & (RB - 1))]) : 0.f;
               }
-              (op + k * HW)[lane] = va * w0[k] + vb * w1w[k];
+              (out + uniform(op + k * HW))[lane] = va * w0[k] + vb * w1w[k];
             }
           } else {
 #pragma unroll
-            for (int k = 0; k < NT; ++k) (op + k * HW)[lane] = v[k] * w0[k] + v[k + 1] * w1w[k];
+            for (int k = 0; k < NT; ++k) (out + uniform(op + k * HW))[lane] = v[k] * w0[k] + v[k + 1] * w1w[k];
           }
         }
       }
@@ -320,9 +336,20 @@ __global__ __launch_bounds__(LK_THREADS) void lookup_bwd_kernel(const float* __r
   }
 }
 
+// bias[i]: the smallest multiple of widthp[i] with base - (w1 >> i) - RC_SKEW + bias >= 0 for every
+// in-range window (base >= -(2r+1))
+void set_skew_bias(rc_dev_layout& d, int radius) {
+  for (int i = 0; i < d.L; ++i) {
+    const int lo = (2 * radius + 1) + ((d.W1 - 1) >> i) + RC_SKEW;
+    d.bias[i] = (lo + d.widthp[i] - 1) / d.widthp[i] * d.widthp[i];
+  }
+}
+
 template <typename VT, int R>
-int launch_fwd(const void* vol, const rc_dev_layout& d, const float* coords, int cc, float* out,
+int launch_fwd(const void* vol, const rc_dev_layout& d_in, const float* coords, int cc, float* out,
                int mode, hipStream_t st) {
+  rc_dev_layout d = d_in;
+  set_skew_bias(d, R);
   const int chunks = (d.W1 + 63) / 64;
   const int64_t items64 = (int64_t)d.B * d.H * chunks;
   const int n_items = (int)items64;

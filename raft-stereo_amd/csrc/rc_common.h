@@ -52,6 +52,7 @@ struct rc_dev_layout {
   int32_t B;
   int32_t width[RC_MAX_LEVELS];
   int32_t widthp[RC_MAX_LEVELS];
+  int32_t bias[RC_MAX_LEVELS];  // lookup only: multiple of widthp that makes every skew argument >= 0
   int64_t offset[RC_MAX_LEVELS];
 };
 
@@ -66,6 +67,7 @@ static inline rc_dev_layout rc_to_dev(const rc_layout* lay) {
   for (int i = 0; i < RC_MAX_LEVELS; ++i) {
     d.width[i] = lay->width[i];
     d.widthp[i] = lay->widthp[i];
+    d.bias[i] = 0;
     d.offset[i] = lay->offset[i];
   }
   return d;
