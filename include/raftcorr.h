@@ -60,24 +60,26 @@ enum {
 };
 
 /*
- * Private layout of the correlation pyramid ("blocked skew", disparity-major):
- * level i of an image row (b,h) is a [widthp[i]][W1] matrix whose row index is the skew
- *     s = (w2 - (w1 >> i) - 17) mod widthp[i]            (widthp = width rounded up to 8)
- * i.e. minus the level-i disparity, so neighbouring pixels with similar disparity use the
- * same skew rows.  Rows are stored in blocks of rb = 16 / element-size rows, interleaved per
- * pixel: element (b,h,w1,w2) of level i lives at
- *     offset[i] + (((b*H + h) * (widthp[i]/rb) + s / rb) * pitch + w1) * rb + s % rb
- * A pixel's 2r+2 taps are then 2-3 aligned 16-byte pieces, and for a fixed piece the pixels of
- * a wave read one contiguous 1 KiB run (16 bytes per lane).  The constant 17 keeps the zone
- * where a tap window wraps around the modulus at disparities of -12..-21 level-i pixels, and
- * makes the rows a build tile completes per chunk start on a block boundary.
- * Nothing outside this library and its Python wrapper may index the pyramid.
+ * Private layout of the correlation pyramid ("group-skewed blocks"):
+ * the column of pixel (b,h,w1) at level i -- its width[i] correlations against w2 = 0.. --
+ * is cut into groups of rb = 16 / element-size consecutive w2, one 16-byte block each.  Group
+ * g = w2 / rb of that pixel is stored in block row
+ *     sb = (g - ((w1 >> i) / rb) + nb - 32 / rb) mod nb,          nb = widthp[i] / rb,
+ * and element (b,h,w1,w2) of level i lives at
+ *     offset[i] + (((b*H + h) * nb + sb) * pitch + w1) * rb + w2 % rb.
+ * Consequences: (1) the 2r+2 taps of a lookup are 2-3 whole blocks, and neighbouring pixels
+ * with similar disparity read neighbouring blocks of the same block rows (16 bytes per lane,
+ * long contiguous runs per wave); (2) the 4 consecutive w2 an MFMA lane owns after the build are
+ * half (16-bit) or all (f32) of one block, so the build writes the pyramid straight from
+ * registers in full 128-byte lines; (3) the wrap-around of a column sits at disparities of
+ * about -32 level-i pixels.  Nothing outside this library and its Python wrapper may index the
+ * pyramid.
  */
 typedef struct rc_layout {
   int64_t B, H, W1, W2;
   int32_t L;                        /* levels stored (= levels ever read, corr.py:133-134) */
   int32_t pitch;                    /* W1 rounded up to a multiple of 64 pixels */
-  int32_t rb;                       /* skew rows per 16-byte block: 8 (f16/bf16) or 4 (f32) */
+  int32_t rb;                       /* w2 per 16-byte block: 8 (f16/bf16) or 4 (f32) */
   int32_t dtype;                    /* element type the layout was made for */
   int32_t width[RC_MAX_LEVELS];     /* W2 >> i */
   int32_t widthp[RC_MAX_LEVELS];    /* width rounded up to a multiple of 8 */

@@ -10,7 +10,7 @@ RC_MAX_LEVELS = 4
 RC_MAX_RADIUS = 8
 RC_F32, RC_F16, RC_BF16 = 0, 1, 2
 RC_COORD_EXACT, RC_COORD_GRIDSAMPLE = 0, 1
-RC_SKEW = 17
+RC_WRAP_ROWS = 32
 
 LIB_NAME = "libraftcorr_hip.so"
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)

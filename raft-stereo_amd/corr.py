@@ -180,12 +180,13 @@ class CorrBlock1DHip:
         lay = layout or self.layout
         vol = self.volume if volume is None else volume
         Wi, WiP, pitch, rb = lay.width[i], lay.widthp[i], lay.pitch, lay.rb
+        nb = WiP // rb
         n = self.B * self.H * WiP * pitch
-        lvl = vol[lay.offset[i]:lay.offset[i] + n].view(self.B, self.H, WiP // rb, pitch, rb)
+        lvl = vol[lay.offset[i]:lay.offset[i] + n].view(self.B, self.H, nb, pitch, rb)
         w1 = torch.arange(self.W1, device=self.device).view(-1, 1)
         w2 = torch.arange(Wi, device=self.device).view(1, -1)
-        s = (w2 - (w1 >> i) - _lib.RC_SKEW) % WiP
-        return lvl[:, :, s // rb, w1.expand_as(s), s % rb]
+        sb = (w2 // rb - (w1 >> i) // rb + nb - _lib.RC_WRAP_ROWS // rb) % nb
+        return lvl[:, :, sb, w1.expand_as(sb), (w2 % rb).expand_as(sb)]
 
 
 class AltCorrBlock1DHip:

@@ -3,17 +3,16 @@
 // Replaces core/corr.py:111-125,148-156 (CorrBlock1D) and :32-42,53-61 (CorrBlockFast1D) of the
 // reference: einsum('aijk,aijh->ajkh') / sqrt(D), reshape, and the avg_pool2d([1,2]) chain.
 //
-// One workgroup (4 waves) owns one image row (b,h) and a tile of 64 left-image pixels (w1) and
-// sweeps the right-image positions (w2) in chunks of TN.  Per chunk: the f2 chunk [K][TN] is
-// staged global -> registers -> LDS (the next chunk's loads are in flight during the MFMAs),
-// transposed on the way out of LDS by ds_read_b64_tr_b16 (16-bit) so that both MFMA operands
-// are K-major; the f1 tile stays in registers for the whole sweep.  MFMA rows are w2 and MFMA
-// columns are w1, so a lane ends up with 4 consecutive w2 of one pixel: levels 1 and 2 of the
-// pyramid are in-register means, level 3 needs one cross-lane exchange.  All levels are
-// scattered into LDS rings indexed by the unwrapped skew row u = w2_i - (w1 >> i) - 17, stored
-// like the pyramid itself ([row block][pixel][rows of the block]); once the rows of a block are
-// complete for all 64 pixels of the tile the block is flushed with 16-byte stores, 1 KiB
-// contiguous per wave.
+// One workgroup (4 waves) owns one image row (b,h) and a tile of 128 left-image pixels (w1), 32
+// per wave, and sweeps the right-image positions (w2) in chunks of TN (64 for 16-bit inputs, 32
+// for f32).  Per chunk the f2 chunk [K][TN] is staged global -> registers -> LDS (the next
+// chunk's loads are in flight during the MFMAs) and transposed on the way out of LDS by
+// ds_read_b64_tr_b16 (16-bit) so that both MFMA operands are K-major; the f1 tile stays in
+// registers for the whole sweep.  MFMA rows are w2 and MFMA columns are w1, so a lane ends up
+// with 4 consecutive, 4-aligned w2 of one pixel: half (16-bit) or all (f32) of one 16-byte block
+// of the rc_layout.  Halves are paired, and the pooled levels are assembled, with
+// v_permlane16_swap / v_permlane32_swap (no LDS), and every level is written straight from
+// registers: each store instruction of a wave writes whole, aligned 128-byte lines.
 #include "rc_common.h"
 
 #include <math.h>
@@ -22,7 +21,8 @@
 namespace {
 
 constexpr int BT = 256;    // threads per workgroup
-constexpr int TM = 64;     // w1 tile
+constexpr int TW = 32;     // w1 columns per wave
+constexpr int TM = 128;    // w1 tile of a workgroup
 constexpr int KMAX = 256;  // feature depth held on chip
 
 typedef short s4v __attribute__((ext_vector_type(4)));
@@ -39,25 +39,17 @@ template <> __device__ __forceinline__ f4v mfma16<rc_bf16>(s8v a, s8v b, f4v c) 
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8v, a), __builtin_bit_cast(b8v, b), c, 0, 0, 0);
 }
 
-template <typename T, typename VT, int TN> struct build_cfg {
+template <typename T> struct build_cfg {
   static constexpr bool IS16 = !std::is_same<T, float>::value;
   static constexpr int ESZ = sizeof(T);
   static constexpr int EPS = 16 / ESZ;            // elements per 16-byte segment
-  static_assert(TN * ESZ == 128, "a staged row is 128 bytes");
-  static constexpr int PF = TN + (IS16 ? 16 : 16);  // LDS row pitch (elements) of the staged tile
+  static constexpr int TN = 128 / ESZ;            // w2 per chunk: a staged row is 128 bytes
+  static constexpr int PF = TN + 16;              // LDS row pitch (elements) of the staged tile
   static constexpr int KSTEP = IS16 ? 32 : 4;
   static constexpr int NKS = KMAX / KSTEP;        // k-steps: 8 (16-bit) or 64 (f32)
-  static constexpr int AT = TN / 32;              // 16-row (w2) MFMA tiles per wave
-  static constexpr int RB = 16 / (int)sizeof(VT);  // skew rows per 16-byte block of the pyramid
-  static constexpr int RING_ROWS = 128 + 64 + 32 + 16;
-  static constexpr int LDSF_BYTES = KMAX * PF * ESZ;
-  static constexpr int RING_BYTES = RING_ROWS * TM * (int)sizeof(VT);
-  static constexpr int LDS_BYTES = LDSF_BYTES + RING_BYTES;
+  static constexpr int NRT = TN / 16;             // 16-row (w2) MFMA tiles per chunk: 4 or 2
+  static constexpr int LDS_BYTES = KMAX * PF * ESZ;
 };
-
-__device__ __forceinline__ int ring_row0(int level) {  // first row of ring `level` in the ring area
-  return level == 0 ? 0 : level == 1 ? 128 : level == 2 ? 192 : 224;
-}
 
 // ---- staging: one [K][128-byte] tile, global -> registers (8 x 16 B per thread) -> LDS
 template <typename T>
@@ -112,14 +104,178 @@ __device__ __forceinline__ s8v tr_frag(const short* ldsF, int kb, int col_off) {
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <typename T, typename VT, int TN>
+// ---- cross-lane exchanges between the four 16-lane rows of a wave (gfx950)
+// swap16: rows 1 and 3 of x trade places with rows 0 and 2 of y;  swap32: rows 2,3 of x with rows 0,1 of y
+__device__ __forceinline__ void swap16(uint32_t& x, uint32_t& y) {
+  const auto r = __builtin_amdgcn_permlane16_swap(x, y, false, false);
+  x = r[0];
+  y = r[1];
+}
+__device__ __forceinline__ void swap32(uint32_t& x, uint32_t& y) {
+  const auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+  x = r[0];
+  y = r[1];
+}
+// 4x4 transpose over lane rows: afterwards lane row g holds in r[p] what lane row p held in r[g]
+__device__ __forceinline__ void transpose_rows(uint32_t (&r)[4]) {
+  swap16(r[0], r[1]);
+  swap16(r[2], r[3]);
+  swap32(r[0], r[2]);
+  swap32(r[1], r[3]);
+}
+
+template <typename VT> __device__ __forceinline__ uint32_t bits16(float v) {
+  return (uint32_t)__builtin_bit_cast(uint16_t, rc_from_float<VT>(v));
+}
+template <typename VT> __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+  return bits16<VT>(lo) | (bits16<VT>(hi) << 16);
+}
+template <typename VT> __device__ __forceinline__ float unpack_lo(uint32_t d) {
+  return rc_to_float(__builtin_bit_cast(VT, (uint16_t)(d & 0xffffu)));
+}
+template <typename VT> __device__ __forceinline__ float unpack_hi(uint32_t d) {
+  return rc_to_float(__builtin_bit_cast(VT, (uint16_t)(d >> 16)));
+}
+
+// Where a wave's blocks go: level bases of this image row, and the block-row arithmetic
+template <typename VT> struct out_map {
+  static constexpr int RB = 16 / (int)sizeof(VT);
+  static constexpr int LG = sizeof(VT) == 4 ? 2 : 3;
+  char* vol;
+  const rc_dev_layout* lay;
+  int64_t row;
+  int W1;
+
+  // byte address of the block of group G of pixel `col` at level i
+  __device__ __forceinline__ char* block(int i, int col, int G) const {
+    const uint32_t nb = (uint32_t)(lay->widthp[i] >> LG), bias = (uint32_t)lay->bias[i];
+    uint32_t t = (uint32_t)(G - ((col >> i) >> LG) - RC_WRAP_ROWS / RB) + bias;  // >= 0 by choice of bias
+    if (bias <= 3 * nb) {  // wave-uniform; always, unless the level is only a few pixels wide
+      t = min(t, t - 2 * nb);
+      t = min(t, t - nb);
+    } else {
+      t %= nb;
+    }
+    return vol + (lay->offset[i] + ((row * nb + t) * lay->pitch + col) * RB) * (int64_t)sizeof(VT);
+  }
+  __device__ __forceinline__ bool ok(int i, int col, int G) const {
+    return col < W1 && G < (lay->widthp[i] >> LG);
+  }
+  __device__ __forceinline__ void store16(int i, int col, int G, uint32_t a, uint32_t b, uint32_t c, uint32_t d) const {
+    if (ok(i, col, G)) *reinterpret_cast<uint4*>(block(i, col, G)) = make_uint4(a, b, c, d);
+  }
+  __device__ __forceinline__ void store8(int i, int col, int G, int half, uint32_t a, uint32_t b) const {
+    if (ok(i, col, G)) *reinterpret_cast<uint2*>(block(i, col, G) + 8 * half) = make_uint2(a, b);
+  }
+};
+
+// ---- epilogue, 16-bit pyramid: a 64 (w2) x 32 (w1) wave tile, acc[rt][ct], lane (g, li) holds rows
+// n0 + 16 rt + 4 g + {0..3} of column cw + 16 ct + li.  Levels >= 1 are means of the already
+// rounded lower level (what avg_pool2d on a 16-bit volume does).
+template <typename VT>
+__device__ __forceinline__ void epilogue16(const f4v (&acc)[4][2], float scale, const out_map<VT>& om, int L,
+                                           int n0, int cw) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
+  const int col_sw = cw + 16 * (g & 1) + li;  // column a lane serves after a swap16 between the column tiles
+  float p1[4][2][2];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    uint32_t x[2][2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = rc_round_as<VT>(acc[rt][ct][r] * scale);
+      x[ct][0] = pack2<VT>(v[0], v[1]);
+      x[ct][1] = pack2<VT>(v[2], v[3]);
+      p1[rt][ct][0] = rc_round_as<VT>(0.5f * (v[0] + v[1]));
+      p1[rt][ct][1] = rc_round_as<VT>(0.5f * (v[2] + v[3]));
+    }
+    // lane rows 0,2 collect the 8-row blocks of column tile 0, lane rows 1,3 those of column tile 1
+    swap16(x[0][0], x[1][0]);
+    swap16(x[0][1], x[1][1]);
+    om.store16(0, col_sw, ((n0 + 16 * rt) >> 3) + (g >> 1), x[0][0], x[0][1], x[1][0], x[1][1]);
+  }
+  if (L < 2) return;
+  float p2[4][2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    uint32_t q[4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      q[rt] = pack2<VT>(p1[rt][ct][0], p1[rt][ct][1]);
+      p2[rt][ct] = rc_round_as<VT>(0.5f * (p1[rt][ct][0] + p1[rt][ct][1]));
+    }
+    transpose_rows(q);  // lane row g: the level-1 block of row tile g
+    om.store16(1, cw + 16 * ct + li, (n0 >> 4) + g, q[0], q[1], q[2], q[3]);
+  }
+  if (L < 3) return;
+  uint32_t w[4];  // w[ct + 2 m] = level-2 values of row tiles 2m, 2m+1: block elements g and 4 + g
+#pragma unroll
+  for (int j = 0; j < 4; ++j) w[j] = pack2<VT>(p2[2 * (j >> 1)][j & 1], p2[2 * (j >> 1) + 1][j & 1]);
+  transpose_rows(w);  // lane row j: w[p] = elements (p, 4 + p) of the block of (column tile j & 1, m = j >> 1)
+  const uint32_t d0 = __builtin_amdgcn_perm(w[1], w[0], 0x05040100u), d1 = __builtin_amdgcn_perm(w[3], w[2], 0x05040100u);
+  const uint32_t d2 = __builtin_amdgcn_perm(w[1], w[0], 0x07060302u), d3 = __builtin_amdgcn_perm(w[3], w[2], 0x07060302u);
+  om.store16(2, col_sw, (n0 >> 5) + (g >> 1), d0, d1, d2, d3);
+  if (L < 4) return;
+  const float q0 = rc_round_as<VT>(0.5f * (unpack_lo<VT>(d0) + unpack_hi<VT>(d0)));
+  const float q1 = rc_round_as<VT>(0.5f * (unpack_lo<VT>(d1) + unpack_hi<VT>(d1)));
+  const float q2 = rc_round_as<VT>(0.5f * (unpack_lo<VT>(d2) + unpack_hi<VT>(d2)));
+  const float q3 = rc_round_as<VT>(0.5f * (unpack_lo<VT>(d3) + unpack_hi<VT>(d3)));
+  om.store8(3, col_sw, n0 >> 6, g >> 1, pack2<VT>(q0, q1), pack2<VT>(q2, q3));
+}
+
+// ---- epilogue, f32 pyramid: a 32 (w2) x 32 (w1) wave tile (two row tiles), n0 a multiple of 32.
+// A lane's 4 rows are one whole block of level 0.
+__device__ __forceinline__ void epilogue32(const f4v& a00, const f4v& a01, const f4v& a10, const f4v& a11,
+                                           float scale, const out_map<float>& om, int L, int n0, int cw) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
+  const int col_sw = cw + 16 * (g & 1) + li;
+  const f4v* acc[2][2] = {{&a00, &a01}, {&a10, &a11}};
+  float p1[2][2][2];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = (*acc[rt][ct])[r] * scale;
+      om.store16(0, cw + 16 * ct + li, ((n0 + 16 * rt) >> 2) + g, __float_as_uint(v[0]), __float_as_uint(v[1]),
+                 __float_as_uint(v[2]), __float_as_uint(v[3]));
+      p1[rt][ct][0] = 0.5f * (v[0] + v[1]);
+      p1[rt][ct][1] = 0.5f * (v[2] + v[3]);
+    }
+  if (L < 2) return;
+  float p2[2][2];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    uint32_t a0 = __float_as_uint(p1[rt][0][0]), b0 = __float_as_uint(p1[rt][0][1]);
+    uint32_t a1 = __float_as_uint(p1[rt][1][0]), b1 = __float_as_uint(p1[rt][1][1]);
+    p2[rt][0] = 0.5f * (p1[rt][0][0] + p1[rt][0][1]);
+    p2[rt][1] = 0.5f * (p1[rt][1][0] + p1[rt][1][1]);
+    swap16(a0, a1);
+    swap16(b0, b1);
+    om.store16(1, col_sw, (((n0 >> 1) + 8 * rt) >> 2) + (g >> 1), a0, b0, a1, b1);
+  }
+  if (L < 3) return;
+  uint32_t r[4];  // r[ct + 2 rt]
+#pragma unroll
+  for (int j = 0; j < 4; ++j) r[j] = __float_as_uint(p2[j >> 1][j & 1]);
+  transpose_rows(r);  // lane row j: the level-2 block of (column tile j & 1, row tile j >> 1)
+  om.store16(2, col_sw, (n0 >> 4) + (g >> 1), r[0], r[1], r[2], r[3]);
+  if (L < 4) return;
+  const float q0 = 0.5f * (__uint_as_float(r[0]) + __uint_as_float(r[1]));
+  const float q1 = 0.5f * (__uint_as_float(r[2]) + __uint_as_float(r[3]));
+  om.store8(3, col_sw, n0 >> 5, g >> 1, __float_as_uint(q0), __float_as_uint(q1));
+}
+
+template <typename T, typename VT>
 __global__ __launch_bounds__(BT) void build_kernel(const T* __restrict__ f1, const T* __restrict__ f2,
                                                    VT* __restrict__ vol, rc_dev_layout lay, int D, float scale,
                                                    int n_tiles, int n_rows, bool vec1, bool vec2) {
-  using C = build_cfg<T, VT, TN>;
+  using C = build_cfg<T>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* ldsF = reinterpret_cast<T*>(smem);
-  VT* ring = reinterpret_cast<VT*>(smem + C::LDSF_BYTES);
 
   // XCD-aware mapping: the tiles of one image row get block ids congruent mod 8 (one XCD, one
   // L2), since they all re-read that row's f2.
@@ -134,7 +290,7 @@ __global__ __launch_bounds__(BT) void build_kernel(const T* __restrict__ f1, con
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, li = lane & 15;
-  const int wm = wave & 1, wn = wave >> 1;  // wave's w1 half / w2 half
+  const int cw = c0 + wave * TW;  // first w1 column of this wave
   const int nk = (D + C::KSTEP - 1) / C::KSTEP;
 
   const T* f1row = f1 + ((int64_t)b * D * lay.H + h) * W1;
@@ -147,84 +303,68 @@ __global__ __launch_bounds__(BT) void build_kernel(const T* __restrict__ f1, con
   s8v bfrag16[C::IS16 ? C::NKS : 1][2];
   float bfrag32[C::IS16 ? 1 : C::NKS][2];
   if constexpr (C::IS16) {
-    stage_load<T>(regs, f1row, ks1, W1, c0, D, vec1);
-    stage_store<T, C::PF>(regs, ldsF);
-    stage_load<T>(regs, f2row, ks2, W2, 0, D, vec2);  // chunk 0 of f2, in flight
-    __syncthreads();
+    // the 128 columns pass through the staging tile in two halves of 64
 #pragma unroll
-    for (int kb = 0; kb < C::NKS; ++kb) {
-      if (kb < nk) {
-        bfrag16[kb][0] = tr_frag<C::PF>(reinterpret_cast<const short*>(ldsF), kb, wm * 32);
-        bfrag16[kb][1] = tr_frag<C::PF>(reinterpret_cast<const short*>(ldsF), kb, wm * 32 + 16);
-      } else {
-        bfrag16[kb][0] = (s8v)(0);
-        bfrag16[kb][1] = (s8v)(0);
+    for (int half = 0; half < 2; ++half) {
+      stage_load<T>(regs, f1row, ks1, W1, c0 + 64 * half, D, vec1);
+      if (half) __syncthreads();  // the first half's fragments have been read
+      stage_store<T, C::PF>(regs, ldsF);
+      __syncthreads();
+      if ((wave >> 1) == half) {
+#pragma unroll
+        for (int kb = 0; kb < C::NKS; ++kb) {
+          if (kb < nk) {
+            bfrag16[kb][0] = tr_frag<C::PF>(reinterpret_cast<const short*>(ldsF), kb, (wave & 1) * 32);
+            bfrag16[kb][1] = tr_frag<C::PF>(reinterpret_cast<const short*>(ldsF), kb, (wave & 1) * 32 + 16);
+          } else {
+            bfrag16[kb][0] = (s8v)(0);
+            bfrag16[kb][1] = (s8v)(0);
+          }
+        }
       }
     }
+    stage_load<T>(regs, f2row, ks2, W2, 0, D, vec2);  // chunk 0 of f2, in flight
   } else {
     stage_load<T>(regs, f2row, ks2, W2, 0, D, vec2);
 #pragma unroll
     for (int ks = 0; ks < C::NKS; ++ks) {
 #pragma unroll
-      for (int bt = 0; bt < 2; ++bt) {
-        const int k = ks * 4 + g, w1 = c0 + wm * 32 + bt * 16 + li;
-        bfrag32[ks][bt] = (k < D && w1 < W1) ? (float)f1row[(int64_t)k * ks1 + w1] : 0.f;
+      for (int ct = 0; ct < 2; ++ct) {
+        const int k = ks * 4 + g, w1 = cw + ct * 16 + li;
+        bfrag32[ks][ct] = (k < D && w1 < W1) ? (float)f1row[(int64_t)k * ks1 + w1] : 0.f;
       }
     }
   }
 
-  const int n_chunks = (W2 + TN - 1) / TN;
-  const int64_t rowblk = (int64_t)row;
+  out_map<VT> om;
+  om.vol = reinterpret_cast<char*>(vol);
+  om.lay = &lay;
+  om.row = row;
+  om.W1 = W1;
 
-  // ring cell of unwrapped skew row u (level i), tile column w1l
-  auto ring_at = [&](int i, int u, int w1l) -> VT* {
-    const int rs = u & ((128 >> i) - 1);
-    return ring + ((ring_row0(i) + (rs & ~(C::RB - 1))) * TM + w1l * C::RB + (rs & (C::RB - 1)));
-  };
-
-  // flush `nblk` row blocks of level i starting at skew row ulo (a multiple of RB) to global memory
-  auto flush = [&](int i, int ulo, int nblk) {
-    const int Wi = lay.width[i], WiP = lay.widthp[i];
-    VT* lvl = vol + lay.offset[i] + (rowblk * (WiP / C::RB)) * lay.pitch * C::RB;
-    for (int it = threadIdx.x; it < nblk * TM; it += BT) {
-      const int blk = it >> 6, w1l = it & 63;
-      const int u0 = ulo + blk * C::RB;
-      const int w20 = u0 + ((c0 + w1l) >> i) + RC_SKEW;  // w2 of the block's first row for this pixel
-      if (w20 + C::RB - 1 < 0 || w20 >= Wi) continue;     // no cell of this block exists
-      const VT* src = ring_at(i, u0, w1l);
-      VT* dst = lvl + ((int64_t)(rc_pmod(u0, WiP) / C::RB) * lay.pitch + c0 + w1l) * C::RB;
-      if (w20 >= 0 && w20 + C::RB - 1 < Wi) {
-        *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
-      } else {
-#pragma unroll
-        for (int e = 0; e < C::RB; ++e)
-          if ((unsigned)(w20 + e) < (unsigned)Wi) dst[e] = src[e];
-      }
-    }
-  };
-
+  const int n_chunks = (W2 + C::TN - 1) / C::TN;
   for (int c = 0; c < n_chunks; ++c) {
-    const int n0 = c * TN;
-    __syncthreads();  // previous readers of ldsF and of the rings are done
+    const int n0 = c * C::TN;
+    __syncthreads();  // previous readers of ldsF are done
     stage_store<T, C::PF>(regs, ldsF);
     __syncthreads();
-    if (c + 1 < n_chunks) stage_load<T>(regs, f2row, ks2, W2, n0 + TN, D, vec2);
+    if (c + 1 < n_chunks) stage_load<T>(regs, f2row, ks2, W2, n0 + C::TN, D, vec2);
 
-    f4v acc[C::AT][2];
+    f4v acc[C::NRT][2];
 #pragma unroll
-    for (int at = 0; at < C::AT; ++at) {
-      acc[at][0] = (f4v)(0.f);
-      acc[at][1] = (f4v)(0.f);
+    for (int rt = 0; rt < C::NRT; ++rt) {
+      acc[rt][0] = (f4v)(0.f);
+      acc[rt][1] = (f4v)(0.f);
     }
     if constexpr (C::IS16) {
 #pragma unroll
       for (int kb = 0; kb < C::NKS; ++kb) {
         if (kb < nk) {
 #pragma unroll
-          for (int at = 0; at < C::AT; ++at) {
-            const s8v a = tr_frag<C::PF>(reinterpret_cast<const short*>(ldsF), kb, wn * (TN / 2) + at * 16);
-            acc[at][0] = mfma16<T>(a, bfrag16[kb][0], acc[at][0]);
-            acc[at][1] = mfma16<T>(a, bfrag16[kb][1], acc[at][1]);
+          for (int rt = 0; rt < C::NRT; ++rt) {
+            const s8v a = tr_frag<C::PF>(reinterpret_cast<const short*>(ldsF), kb, rt * 16);
+            acc[rt][0] = mfma16<T>(a, bfrag16[kb][0], acc[rt][0]);
+            acc[rt][1] = mfma16<T>(a, bfrag16[kb][1], acc[rt][1]);
           }
         }
       }
@@ -234,60 +374,24 @@ __global__ __launch_bounds__(BT) void build_kernel(const T* __restrict__ f1, con
       for (int ks = 0; ks < C::NKS; ++ks) {
         if (ks < nk) {
 #pragma unroll
-          for (int at = 0; at < C::AT; ++at) {
-            const float a = lf[(ks * 4 + g) * C::PF + wn * (TN / 2) + at * 16 + li];
-            acc[at][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfrag32[ks][0], acc[at][0], 0, 0, 0);
-            acc[at][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfrag32[ks][1], acc[at][1], 0, 0, 0);
+          for (int rt = 0; rt < C::NRT; ++rt) {
+            const float a = lf[(ks * 4 + g) * C::PF + rt * 16 + li];
+            acc[rt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfrag32[ks][0], acc[rt][0], 0, 0, 0);
+            acc[rt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfrag32[ks][1], acc[rt][1], 0, 0, 0);
           }
         }
       }
     }
 
-    // ---- epilogue: scale, round to the storage type, pool, scatter into the rings
+    // ---- epilogue: scale, round to the storage type, pool, write every level from registers
+    if constexpr (std::is_same<VT, float>::value) {
 #pragma unroll
-    for (int at = 0; at < C::AT; ++at) {
-#pragma unroll
-      for (int bt = 0; bt < 2; ++bt) {
-        const int w1l = wm * 32 + bt * 16 + li;      // column inside the tile
-        const int w1 = c0 + w1l;
-        const int w2b = n0 + wn * (TN / 2) + at * 16 + 4 * g;  // first of this lane's 4 w2
-        float v0[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          v0[r] = rc_round_as<VT>(acc[at][bt][r] * scale);
-          *ring_at(0, w2b + r - w1 - RC_SKEW, w1l) = rc_from_float<VT>(v0[r]);
-        }
-        if (L > 1) {
-          const float p10 = rc_round_as<VT>(0.5f * (v0[0] + v0[1]));
-          const float p11 = rc_round_as<VT>(0.5f * (v0[2] + v0[3]));
-          const int u1 = (w2b >> 1) - (w1 >> 1) - RC_SKEW;
-          *ring_at(1, u1, w1l) = rc_from_float<VT>(p10);
-          *ring_at(1, u1 + 1, w1l) = rc_from_float<VT>(p11);
-          if (L > 2) {
-            const float p2 = rc_round_as<VT>(0.5f * (p10 + p11));
-            *ring_at(2, (w2b >> 2) - (w1 >> 2) - RC_SKEW, w1l) = rc_from_float<VT>(p2);
-            if (L > 3) {
-              const float other = __shfl_xor(p2, 16);
-              const float p3 = rc_round_as<VT>(0.5f * (p2 + other));
-              if ((g & 1) == 0) *ring_at(3, (w2b >> 3) - (w1 >> 3) - RC_SKEW, w1l) = rc_from_float<VT>(p3);
-            }
-          }
-        }
-      }
+      for (int hh = 0; hh < C::NRT / 2; ++hh)
+        epilogue32(acc[2 * hh][0], acc[2 * hh][1], acc[2 * hh + 1][0], acc[2 * hh + 1][1], scale, om, L,
+                   n0 + 32 * hh, cw);
+    } else {
+      epilogue16<VT>(acc, scale, om, L, n0, cw);
     }
-    __syncthreads();
-
-    // ---- flush the row blocks completed by this chunk (they start on a block boundary)
-    for (int i = 0; i < L; ++i) {
-      const int Mi = TM >> i, TNi = TN >> i;
-      flush(i, (n0 >> i) - (c0 >> i) - Mi - (RC_SKEW - 1), TNi / C::RB);
-    }
-  }
-  // rows that never complete inside the tile (their other part belongs to the wrapped range)
-  const int n0l = (n_chunks - 1) * TN;
-  for (int i = 0; i < L; ++i) {
-    const int Mi = TM >> i, TNi = TN >> i;
-    flush(i, (n0l >> i) + TNi - (c0 >> i) - Mi - (RC_SKEW - 1), (Mi + C::RB - 1) / C::RB);
   }
 }
 
@@ -310,7 +414,7 @@ __global__ void naive_corr_kernel(const T* __restrict__ f1, const T* __restrict_
   float acc = 0.f;
   for (int k = 0; k < D; ++k)
     acc = fmaf(rc_to_float(p1[(int64_t)k * lay.H * W1]), rc_to_float(p2[(int64_t)k * lay.H * W2]), acc);
-  vol[rc_cell<RB>(lay, 0, bh, rc_pmod(w2 - w1 - RC_SKEW, lay.widthp[0]), w1)] = rc_from_float<VT>(acc * scale);
+  vol[rc_cell<RB>(lay, 0, bh, w1, w2)] = rc_from_float<VT>(acc * scale);
 }
 
 template <typename VT>
@@ -323,11 +427,9 @@ __global__ void naive_pool_kernel(VT* __restrict__ vol, rc_dev_layout lay, int l
   const int64_t t = idx / W1;
   const int w2 = (int)(t % Wi);
   const int64_t bh = t / Wi;
-  const int qp = w1 >> (level - 1), WpP = lay.widthp[level - 1];
-  const float a = rc_to_float(vol[rc_cell<RB>(lay, level - 1, bh, rc_pmod(2 * w2 - qp - RC_SKEW, WpP), w1)]);
-  const float bb = rc_to_float(vol[rc_cell<RB>(lay, level - 1, bh, rc_pmod(2 * w2 + 1 - qp - RC_SKEW, WpP), w1)]);
-  vol[rc_cell<RB>(lay, level, bh, rc_pmod(w2 - (w1 >> level) - RC_SKEW, lay.widthp[level]), w1)] =
-      rc_from_float<VT>(0.5f * (a + bb));
+  const float a = rc_to_float(vol[rc_cell<RB>(lay, level - 1, bh, w1, 2 * w2)]);
+  const float bb = rc_to_float(vol[rc_cell<RB>(lay, level - 1, bh, w1, 2 * w2 + 1)]);
+  vol[rc_cell<RB>(lay, level, bh, w1, w2)] = rc_from_float<VT>(0.5f * (a + bb));
 }
 
 template <typename T, typename VT>
@@ -347,10 +449,20 @@ int launch_naive(const void* f1, const void* f2, void* vol, const rc_layout* lay
   return rc;
 }
 
-template <typename T, typename VT, int TN>
+// bias[i] for the build's block-row arithmetic: the smallest multiple of the level's block-row
+// count with G - (col >> i) / RB - RC_WRAP_ROWS / RB + bias >= 0 for every group G >= 0
+void set_build_bias(rc_dev_layout& d, int rb) {
+  for (int i = 0; i < d.L; ++i) {
+    const int nb = d.widthp[i] / rb;
+    const int lo = (((d.pitch + TM) >> i) / rb) + RC_WRAP_ROWS / rb;
+    d.bias[i] = (lo + nb - 1) / nb * nb;
+  }
+}
+
+template <typename T, typename VT>
 int launch_build(const void* f1, const void* f2, void* vol, const rc_layout* lay, int D, float scale,
                  hipStream_t st) {
-  using C = build_cfg<T, VT, TN>;
+  using C = build_cfg<T>;
   static bool attr_set[64] = {};  // per device; raising the limit is idempotent, races are harmless
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
@@ -358,7 +470,7 @@ int launch_build(const void* f1, const void* f2, void* vol, const rc_layout* lay
     return RC_ENODEVICE;
   }
   if (!attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&build_kernel<T, VT, TN>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&build_kernel<T, VT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     if (e != hipSuccess) {
       rc_set_error("hipFuncSetAttribute(%d bytes LDS): %s", C::LDS_BYTES, hipGetErrorString(e));
@@ -366,7 +478,8 @@ int launch_build(const void* f1, const void* f2, void* vol, const rc_layout* lay
     }
     attr_set[dev] = true;
   }
-  const rc_dev_layout d = rc_to_dev(lay);
+  rc_dev_layout d = rc_to_dev(lay);
+  set_build_bias(d, 16 / (int)sizeof(VT));
   const int n_tiles = (int)((lay->W1 + TM - 1) / TM);
   const int n_rows = (int)(lay->B * lay->H);
   const int64_t blocks = (int64_t)((n_rows + 7) / 8) * 8 * n_tiles;
@@ -374,7 +487,7 @@ int launch_build(const void* f1, const void* f2, void* vol, const rc_layout* lay
   constexpr int EPS = 16 / (int)sizeof(T);
   const bool vec1 = (lay->W1 % EPS == 0) && (((uintptr_t)f1) % 16 == 0);
   const bool vec2 = (lay->W2 % EPS == 0) && (((uintptr_t)f2) % 16 == 0);
-  hipLaunchKernelGGL((build_kernel<T, VT, TN>), dim3((unsigned)blocks), dim3(BT), C::LDS_BYTES, st,
+  hipLaunchKernelGGL((build_kernel<T, VT>), dim3((unsigned)blocks), dim3(BT), C::LDS_BYTES, st,
                      (const T*)f1, (const T*)f2, (VT*)vol, d, D, scale, n_tiles, n_rows, vec1, vec2);
   return rc_check_launch("rc_build_pyramid");
 }
@@ -393,15 +506,15 @@ static int build_dispatch(const void* f1, const void* f2, void* vol, const rc_la
   const bool naive = force_naive || D > KMAX;
   const int iD = (int)D;
   const int vol_dtype = lay->dtype;
-#define RC_BUILD_CASE(IN, VOL, T, VT, TN)                                            \
+#define RC_BUILD_CASE(IN, VOL, T, VT)                                                \
   if (in_dtype == IN && vol_dtype == VOL)                                            \
     return naive ? launch_naive<T, VT>(f1, f2, vol, lay, iD, scale, st)              \
-                 : launch_build<T, VT, TN>(f1, f2, vol, lay, iD, scale, st);
-  RC_BUILD_CASE(RC_F32, RC_F32, float, float, 32)
-  RC_BUILD_CASE(RC_F16, RC_F16, rc_half, rc_half, 64)
-  RC_BUILD_CASE(RC_BF16, RC_BF16, rc_bf16, rc_bf16, 64)
-  RC_BUILD_CASE(RC_F16, RC_F32, rc_half, float, 64)
-  RC_BUILD_CASE(RC_BF16, RC_F32, rc_bf16, float, 64)
+                 : launch_build<T, VT>(f1, f2, vol, lay, iD, scale, st);
+  RC_BUILD_CASE(RC_F32, RC_F32, float, float)
+  RC_BUILD_CASE(RC_F16, RC_F16, rc_half, rc_half)
+  RC_BUILD_CASE(RC_BF16, RC_BF16, rc_bf16, rc_bf16)
+  RC_BUILD_CASE(RC_F16, RC_F32, rc_half, float)
+  RC_BUILD_CASE(RC_BF16, RC_F32, rc_bf16, float)
 #undef RC_BUILD_CASE
   rc_set_error("unsupported (in_dtype=%d, pyramid dtype=%d) combination", in_dtype, vol_dtype);
   return RC_EUNSUPPORTED;

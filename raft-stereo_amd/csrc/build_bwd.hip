@@ -2,7 +2,7 @@
 //
 // Autograd of core/corr.py:119-125 (avg_pool2d chain) and :154-156 (einsum, / sqrt(D)).
 // Two steps on one stream:
-//   1. unskew_fold: reads every 16-byte row block once (coalesced), folds levels 1..L-1 into level 0
+//   1. unskew_fold: reads every 16-byte block once (coalesced), folds levels 1..L-1 into level 0
 //      (each pooled cell spreads 2^-i of its gradient over its 2^i children), scales by
 //      1/sqrt(D), and writes the dense dC[b,h,w1,w2] and its transpose dCt[b,h,w2,w1] in the
 //      compute type, zero padded to a multiple of 32 along the contraction axis.
@@ -42,22 +42,18 @@ __global__ __launch_bounds__(256) void unskew_fold_kernel(const float* __restric
 
   float wgt = scale;
   for (int i = 0; i < lay.L; ++i) {
-    const int Wi = lay.width[i], WiP = lay.widthp[i];
-    const int q = w1 >> i;
+    const int Wi = lay.width[i], nb = lay.widthp[i] / 4;
     const int nlo = n0 >> i, nhi = min((n0 + UT - 1) >> i, Wi - 1);   // pooled columns of this tile
-    // unwrapped skew rows u = w2 - q - 17 touching the tile, rounded down to a block of 4 rows
-    int ub0 = nlo - ((c0 + UT - 1) >> i) - RC_SKEW;
-    ub0 -= rc_pmod(ub0, 4);
-    const int uhi = nhi - (c0 >> i) - RC_SKEW;
-    const float* lvl = gvol + lay.offset[i] + (bh * (WiP / 4)) * lay.pitch * 4;
-    for (int u0 = ub0 + 4 * rg; u0 <= uhi; u0 += 16) {
-      const int w20 = u0 + q + RC_SKEW;
-      if (w1 < W1 && w20 + 3 >= nlo && w20 <= nhi) {
-        const float4 v4 = *reinterpret_cast<const float4*>(lvl + ((int64_t)(rc_pmod(u0, WiP) / 4) * lay.pitch + w1) * 4);
+    const float* lvl = gvol + lay.offset[i] + (bh * nb) * lay.pitch * 4;
+    if (w1 < W1) {
+      // this pixel's groups of 4 pooled columns that touch the tile, one 16-byte block each
+      for (int g = (nlo >> 2) + rg; g <= (nhi >> 2); g += 4) {
+        const int sb = rc_block_row<4>(g, w1 >> i, nb);
+        const float4 v4 = *reinterpret_cast<const float4*>(lvl + ((int64_t)sb * lay.pitch + w1) * 4);
         const float v[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int w2i = w20 + r;
+          const int w2i = 4 * g + r;
           if (w2i >= nlo && w2i <= nhi) {
             const int base = (w2i << i) - n0;
             for (int e = 0; e < (1 << i); ++e) tile[col][base + e] += v[r] * wgt;

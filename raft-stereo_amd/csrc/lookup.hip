@@ -1,13 +1,16 @@
-// Per-iteration correlation lookup, forward and adjoint, over the blocked-skew pyramid.
+// Per-iteration correlation lookup, forward and adjoint, over the group-skewed blocked pyramid.
 //
 // Replaces core/corr.py:127-146 (reg), core/corr.py:44-51 + sampler/sampler_kernel.cu:19-105
 // (reg_cuda) of the reference.  One launch covers all levels.  A wave owns 64 consecutive
-// pixels of one image row, one pixel per lane.  In the rc_layout a pixel's 2r+2 taps of a
-// level are consecutive skew rows of its own column, stored as aligned 16-byte blocks; the
-// lane loads the 2-3 (f16/bf16) or 3-4 (f32) blocks that cover its window with 16-byte loads
-// and shifts the taps into place in registers.  Pixels with similar disparity use the same row
-// blocks, so each load instruction of the wave reads one contiguous 1 KiB run.  Outputs are
-// written per channel plane, 256 B per wave store.
+// pixels of one image row, one pixel per lane.  In the rc_layout a pixel's column of a level is
+// cut into aligned groups of 8 (f16/bf16) or 4 (f32) consecutive w2, one 16-byte block each,
+// and consecutive groups of a pixel sit in consecutive block rows; a 2r+2 tap window is the
+// 2-3 (16-bit) or 3-4 (f32) blocks that cover it.  The lane loads them with 16-byte loads and
+// shifts the taps into place in registers.  Pixels with similar disparity use the same block
+// rows, so each load instruction of the wave reads a few long contiguous runs.  Everything that
+// does not depend on the lane (row, chunk, level bases, output planes) is kept wave-uniform, so
+// loads and stores use scalar base + 32-bit lane offset addressing.  Outputs are written per
+// channel plane, 256 B per wave store.
 #include "rc_common.h"
 
 namespace {
@@ -19,22 +22,21 @@ template <typename VT> struct vt_info {
   static constexpr int LG = sizeof(VT) == 4 ? 2 : 3;  // log2(RB)
 };
 
+// geometry of a tap window: entries wbase .. wbase + NW - 1, wbase = (first tap) - EXT.  In
+// grid_sample mode the window is one entry wider on both sides, because the reference's fp32
+// coordinate round trip can move a tap across an integer.
+template <int RB, int R, int MODE> struct win_info {
+  static constexpr int NT = 2 * R + 1;
+  static constexpr int EXT = MODE == RC_COORD_GRIDSAMPLE ? 1 : 0;
+  static constexpr int NW = NT + 1 + 2 * EXT;
+  static constexpr int NBLK = (RB - 1 + NW + RB - 1) / RB;  // 16-byte blocks a window can touch
+  static constexpr int ND = NBLK * 4;
+};
+
 __device__ __forceinline__ float half_bits_to_float(uint32_t h, rc_half) {
   return (float)__builtin_bit_cast(rc_half, (uint16_t)h);
 }
 __device__ __forceinline__ float half_bits_to_float(uint32_t h, rc_bf16) { return __uint_as_float(h << 16); }
-
-// (t mod m) in [0, m) for t + bias >= 0, bias a multiple of m (set_skew_bias): two conditional
-// subtractions when t + bias < 4 m (always, unless a level is only a few pixels wide)
-__device__ __forceinline__ int skew_pmod(int t_plus_bias, int m, int bias) {
-  uint32_t r = (uint32_t)t_plus_bias;
-  if (bias <= 3 * m) {  // wave-uniform
-    r = min(r, r - 2u * (uint32_t)m);
-    r = min(r, r - (uint32_t)m);
-    return (int)r;
-  }
-  return (int)(r % (uint32_t)m);
-}
 
 // An offset the compiler must keep in scalar registers (the value is wave-uniform by
 // construction), so that base + uniform(offset) stays a scalar address and the lane index goes
@@ -45,10 +47,51 @@ __device__ __forceinline__ int64_t uniform(int64_t v) {
   return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
+// (t mod nb) for 0 <= t < bias + 2 nb, bias a multiple of nb chosen by set_row_bias
+__device__ __forceinline__ uint32_t row_mod(uint32_t t, uint32_t nb, uint32_t bias) {
+  if (bias <= 2 * nb) {  // wave-uniform; always, unless a level is only a few pixels wide
+    t = min(t, t - 2 * nb);
+    return min(t, t - nb);
+  }
+  return t % nb;
+}
+
+// Block row of the k-th block after row sb0 (< nb), wrapping around the column
+__device__ __forceinline__ uint32_t row_step(uint32_t sb0, uint32_t k, uint32_t nb, bool tiny) {
+  const uint32_t s = sb0 + k;
+  return tiny ? s % nb : min(s, s - nb);  // tiny (nb < blocks per window): wave-uniform
+}
+
+// Per-level window position of one pixel
+struct win_pos {
+  int wbase;      // w2 of window entry 0
+  int o;          // its position inside the first block
+  int g0;         // group (block) of window entry 0
+  uint32_t sb0;   // block row of that group in this pixel's column
+  int nbk;        // index of the last block the window touches
+  bool any_ok;    // the window overlaps the image
+  bool edge;      // some entry is outside the image
+};
+
+template <int RB, int LG, int NW>
+__device__ __forceinline__ win_pos locate_window(int wbase_raw, int w1, int i, int Wi, int nb, int bias) {
+  win_pos p;
+  p.any_ok = (wbase_raw + NW - 1 >= 0) && (wbase_raw < Wi);
+  p.edge = (wbase_raw < 0) || (wbase_raw + NW - 1 >= Wi);
+  p.wbase = wbase_raw;
+  const int wb = p.any_ok ? wbase_raw : 0;  // keeps the group arithmetic small; such lanes output zeros
+  p.g0 = wb >> LG;
+  p.o = wb & (RB - 1);
+  p.nbk = (p.o + NW - 1) >> LG;
+  p.sb0 = row_mod((uint32_t)(p.g0 - ((w1 >> i) >> LG) + nb - RC_WRAP_ROWS / RB + bias), (uint32_t)nb,
+                  (uint32_t)bias);
+  return p;
+}
+
 // v[j] = element (o + j) of the window held in the dwords d[0..ND): shift down by `o` elements
 // with two select stages (+ one byte-align for 16-bit elements)
-template <typename VT, int NT, int ND>
-__device__ __forceinline__ void decode_window(uint32_t (&d)[ND], int o, float (&v)[NT + 1]) {
+template <typename VT, int NW, int ND>
+__device__ __forceinline__ void decode_window(uint32_t (&d)[ND], int o, float (&v)[NW]) {
   const int sh = (sizeof(VT) == 4) ? o : (o >> 1);  // shift in dwords, 0..3
   // (both operands are read into temporaries first: a select between array ELEMENTS would be
   // turned into a dynamically indexed, scratch-backed array by the compiler)
@@ -65,24 +108,22 @@ __device__ __forceinline__ void decode_window(uint32_t (&d)[ND], int o, float (&
   }
   if constexpr (sizeof(VT) == 4) {
 #pragma unroll
-    for (int j = 0; j <= NT; ++j) v[j] = __uint_as_float(d[j]);
+    for (int j = 0; j < NW; ++j) v[j] = __uint_as_float(d[j]);
   } else {
     const uint32_t bsh = (o & 1) * 2;
 #pragma unroll
-    for (int k = 0; 2 * k <= NT; ++k) {
+    for (int k = 0; 2 * k < NW; ++k) {
       const uint32_t t = __builtin_amdgcn_alignbyte(d[k + 1], d[k], bsh);
       v[2 * k] = half_bits_to_float(t & 0xffffu, VT());
-      if (2 * k + 1 <= NT) v[2 * k + 1] = half_bits_to_float(t >> 16, VT());
+      if (2 * k + 1 < NW) v[2 * k + 1] = half_bits_to_float(t >> 16, VT());
     }
   }
 }
 
-// A wave owns 64 consecutive pixels of one image row.  Everything that does not depend on the
-// lane (row, chunk, level bases, output planes) is kept wave-uniform so that loads and stores use
-// scalar base + 32-bit lane offset addressing.  LV > 0 is a compile-time level count: the 16-byte
-// loads of all levels are issued back to back (no branch in between: lanes that do not need a
-// block re-read one they do need), then decoded, interpolated and stored.  LV == 0 takes the level
-// count from the layout and handles one level at a time.
+// LV > 0 is a compile-time level count: the 16-byte loads of all levels are issued back to back
+// (no branch in between: lanes that do not need a block re-read one they do need), then decoded,
+// interpolated and stored.  LV == 0 takes the level count from the layout and handles one level
+// at a time.
 template <typename VT, int R, int MODE, int LV>
 __global__ __launch_bounds__(LK_THREADS) void lookup_fwd_kernel(const VT* __restrict__ vol,
                                                                 rc_dev_layout lay,
@@ -90,10 +131,9 @@ __global__ __launch_bounds__(LK_THREADS) void lookup_fwd_kernel(const VT* __rest
                                                                 int coords_channels,
                                                                 float* __restrict__ out,
                                                                 int chunks_per_row, int n_items) {
-  constexpr int NT = 2 * R + 1;
   constexpr int RB = vt_info<VT>::RB, LG = vt_info<VT>::LG;
-  constexpr int NBLK = (RB + NT + RB - 1) / RB;  // 16-byte blocks a window can touch
-  constexpr int ND = NBLK * 4;
+  using WI = win_info<RB, R, MODE>;
+  constexpr int NT = WI::NT, EXT = WI::EXT, NW = WI::NW, NBLK = WI::NBLK, ND = WI::ND;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int item = blockIdx.x * (LK_THREADS / 64) + wave;  // (row, 64-pixel chunk), wave-uniform
@@ -106,50 +146,36 @@ __global__ __launch_bounds__(LK_THREADS) void lookup_fwd_kernel(const VT* __rest
   const int64_t HW = (int64_t)lay.H * lay.W1;
   constexpr int LB = LV ? LV : 1;  // levels in flight together
   const int L = LV ? LV : lay.L;
-  const uint32_t blk_bytes = (uint32_t)lay.pitch * 16u;  // distance between row blocks of a pixel
+  const uint32_t blk_bytes = (uint32_t)lay.pitch * 16u;  // distance between block rows of a pixel
 
   const float x = (coords + uniform(((int64_t)b * coords_channels) * HW + (int64_t)h * lay.W1 + c0))[lane];
   const int64_t out_u = ((int64_t)b * L * NT) * HW + (int64_t)h * lay.W1 + c0;  // wave-uniform
 
   for (int i0 = 0; i0 < L; i0 += LB) {
     uint32_t d[LB][ND];
-    int base[LB], s0[LB], o[LB];
+    win_pos pos[LB];
     float frac[LB];
-    bool slow[LB], edge[LB];
 
     // ---- phase 1: addresses and loads of LB levels
 #pragma unroll
     for (int j = 0; j < LB; ++j) {
       const int i = i0 + j;
-      {
-        const int Wi = lay.width[i], WiP = lay.widthp[i];
-        const float xi = x * (1.0f / (float)(1 << i));
-        const float xf = floorf(xi);
-        frac[j] = xi - xf;
-        base[j] = rc_safe_int(xf) - R;
-        const bool any_ok = (base[j] + NT >= 0) && (base[j] < Wi);
-        edge[j] = (base[j] < 0) || (base[j] + NT >= Wi);  // some tap is outside the image
-        const int bias = lay.bias[i];
-        const int t = (any_ok ? base[j] - (w1 >> i) - RC_SKEW : 0) + bias;
-        s0[j] = skew_pmod(t, WiP, bias);
-        const bool fast = any_ok && (s0[j] + NT < WiP);
-        slow[j] = any_ok && !fast;  // the window wraps around the modulus (disparity about -12..-21)
-        const int s0c = fast ? s0[j] : 0;
-        o[j] = s0c & (RB - 1);
-        const int blk0 = s0c >> LG;
-        const int nb = fast ? ((o[j] + NT) >> LG) : 0;  // last block this lane needs
-        const char* lvl = reinterpret_cast<const char*>(vol) +
-                          uniform(lay.offset[i] * (int64_t)sizeof(VT) + (int64_t)bh * (WiP >> LG) * blk_bytes);
-        const uint32_t voff = __umul24((uint32_t)blk0, blk_bytes) + (uint32_t)w1 * 16u;
+      const int Wi = lay.width[i], nb = lay.widthp[i] >> LG;
+      const float xi = x * (1.0f / (float)(1 << i));
+      const float xf = floorf(xi);
+      frac[j] = xi - xf;
+      pos[j] = locate_window<RB, LG, NW>(rc_safe_int(xf) - R - EXT, w1, i, Wi, nb, lay.bias[i]);
+      const char* lvl = reinterpret_cast<const char*>(vol) +
+                        uniform(lay.offset[i] * (int64_t)sizeof(VT) + (int64_t)bh * nb * blk_bytes);
+      const bool tiny = nb < NBLK;
 #pragma unroll
-        for (int k = 0; k < NBLK; ++k) {
-          const uint32_t kk = (uint32_t)min(k, nb);
-          const uint4 q = *reinterpret_cast<const uint4*>(lvl + (voff + __umul24(kk, blk_bytes)));
-          d[j][4 * k + 0] = q.x;
-          d[j][4 * k + 1] = q.y;
-          d[j][4 * k + 2] = q.z;
-          d[j][4 * k + 3] = q.w;
-        }
+      for (int k = 0; k < NBLK; ++k) {
+        const uint32_t sb = row_step(pos[j].sb0, (uint32_t)min(k, pos[j].nbk), (uint32_t)nb, tiny);
+        const uint4 q = *reinterpret_cast<const uint4*>(lvl + (__umul24(sb, blk_bytes) + (uint32_t)w1 * 16u));
+        d[j][4 * k + 0] = q.x;
+        d[j][4 * k + 1] = q.y;
+        d[j][4 * k + 2] = q.z;
+        d[j][4 * k + 3] = q.w;
       }
     }
 
@@ -157,62 +183,44 @@ __global__ __launch_bounds__(LK_THREADS) void lookup_fwd_kernel(const VT* __rest
 #pragma unroll
     for (int j = 0; j < LB; ++j) {
       const int i = i0 + j;
-      {
-        const int Wi = lay.width[i], WiP = lay.widthp[i];
-        const int64_t op = out_u + (int64_t)i * NT * HW;  // wave-uniform plane base
-        float v[NT + 1];
-        decode_window<VT, NT, ND>(d[j], o[j], v);
-        if (__builtin_expect(__any(slow[j]), 0)) {
-          if (slow[j]) {
-            const VT* col = vol + lay.offset[i] + ((int64_t)bh * (WiP >> LG) * lay.pitch + w1) * RB;
+      const int Wi = lay.width[i];
+      const int64_t op = out_u + (int64_t)i * NT * HW;  // wave-uniform plane base
+      float v[NW];
+      decode_window<VT, NW, ND>(d[j], pos[j].o, v);
+      if (__any(pos[j].edge)) {  // interior waves skip the zero padding
 #pragma unroll
-            for (int m = 0; m <= NT; ++m) {
-              const int s = (s0[j] + m) % WiP;  // levels narrower than the window wrap more than once
-              v[m] = rc_to_float(col[(int64_t)(s >> LG) * lay.pitch * RB + (s & (RB - 1))]);
-            }
-          }
-        }
-        if (__any(edge[j])) {  // interior waves skip the zero padding
-#pragma unroll
-          for (int m = 0; m <= NT; ++m) v[m] = ((unsigned)(base[j] + m) < (unsigned)Wi) ? v[m] : 0.f;
-        }
+        for (int m = 0; m < NW; ++m) v[m] = ((unsigned)(pos[j].wbase + m) < (unsigned)Wi) ? v[m] : 0.f;
+      }
 
-        if (MODE == RC_COORD_EXACT) {
-          const float a = frac[j], bw = 1.0f - a;
+      if constexpr (MODE == RC_COORD_EXACT) {
+        const float a = frac[j], bw = 1.0f - a;
 #pragma unroll
-          for (int k = 0; k < NT; ++k) (out + uniform(op + k * HW))[lane] = v[k] * bw + v[k + 1] * a;
-        } else {
-          const float xi = x * (1.0f / (float)(1 << i));
-          const float wm1 = (float)(Wi - 1);
-          const int qm = w1 >> i;
-          int i0k[NT];
-          float w0[NT], w1w[NT];
-          bool odd = false;
+        for (int k = 0; k < NT; ++k) (out + uniform(op + k * HW))[lane] = v[k] * bw + v[k + 1] * a;
+      } else {
+        const float xi = x * (1.0f / (float)(1 << i));
+        const float wm1 = (float)(Wi - 1);
+        int dlt[NT];  // where grid_sample's floor landed relative to tap k: -1, 0 or +1
+        float w0[NT], w1w[NT];
+        bool odd = false;
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+          int i0k;
+          rc_gridsample_coords(xi, k - R, wm1, &i0k, &w0[k], &w1w[k]);
+          dlt[k] = i0k - (pos[j].wbase + EXT + k);
+          odd |= (dlt[k] != 0);
+        }
+        if (__builtin_expect(__any(odd), 0)) {
+          // the fp32 round trip moved some tap across an integer: take it from the widened window
 #pragma unroll
           for (int k = 0; k < NT; ++k) {
-            rc_gridsample_coords(xi, k - R, wm1, &i0k[k], &w0[k], &w1w[k]);
-            odd |= (i0k[k] != base[j] + k);
+            const float va = dlt[k] < 0 ? v[k] : (dlt[k] > 0 ? v[k + 2] : v[k + 1]);
+            const float vb = dlt[k] < 0 ? v[k + 1] : (dlt[k] > 0 ? v[k + 3] : v[k + 2]);
+            (out + uniform(op + k * HW))[lane] = va * w0[k] + vb * w1w[k];
           }
-          if (__builtin_expect(__any(odd), 0)) {
-            // the fp32 round trip moved some tap across an integer: fetch those taps directly
-            const VT* col = vol + lay.offset[i] + ((int64_t)bh * (WiP >> LG) * lay.pitch + w1) * RB;
+        } else {
 #pragma unroll
-            for (int k = 0; k < NT; ++k) {
-              float va = v[k], vb = v[k + 1];
-              if (i0k[k] != base[j] + k) {
-                const int wa = i0k[k], wb = i0k[k] + 1;
-                const int sa = rc_pmod(wa - qm - RC_SKEW, WiP), sb = rc_pmod(wb - qm - RC_SKEW, WiP);
-                va = ((unsigned)wa < (unsigned)Wi)
-                         ? rc_to_float(col[(int64_t)(sa >> LG) * lay.pitch * RB + (sa & (RB - 1))]) : 0.f;
-                vb = ((unsigned)wb < (unsigned)Wi)
-                         ? rc_to_float(col[(int64_t)(sb >> LG) * lay.pitch * RB + (sb & (RB - 1))]) : 0.f;
-              }
-              (out + uniform(op + k * HW))[lane] = va * w0[k] + vb * w1w[k];
-            }
-          } else {
-#pragma unroll
-            for (int k = 0; k < NT; ++k) (out + uniform(op + k * HW))[lane] = v[k] * w0[k] + v[k + 1] * w1w[k];
-          }
+          for (int k = 0; k < NT; ++k)
+            (out + uniform(op + k * HW))[lane] = v[k + EXT] * w0[k] + v[k + EXT + 1] * w1w[k];
         }
       }
     }
@@ -220,7 +228,10 @@ __global__ __launch_bounds__(LK_THREADS) void lookup_fwd_kernel(const VT* __rest
 }
 
 // Adjoint: grad_vol (float pyramid, RB = 4) += scatter of grad_out.  The pixel owns its column
-// of every level, so plain read-modify-write of its 16-byte blocks is race free.
+// of every level, so plain read-modify-write of its 16-byte blocks is race free.  Per level the
+// gradient planes and the blocks are loaded first, then updated and stored; blocks of groups that
+// do not exist (window hanging over the image border) are loaded from a valid address and not
+// stored.
 template <int R, int MODE>
 __global__ __launch_bounds__(LK_THREADS) void lookup_bwd_kernel(const float* __restrict__ coords,
                                                                 int coords_channels,
@@ -228,43 +239,57 @@ __global__ __launch_bounds__(LK_THREADS) void lookup_bwd_kernel(const float* __r
                                                                 float* __restrict__ gvol,
                                                                 rc_dev_layout lay, int chunks_per_row,
                                                                 int n_items) {
-  constexpr int NT = 2 * R + 1;
-  constexpr int RB = 4;
-  constexpr int NBLK = (RB + NT + RB - 1) / RB;
-  constexpr int ND = NBLK * 4;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  constexpr int RB = 4, LG = 2;
+  using WI = win_info<RB, R, MODE>;
+  constexpr int NT = WI::NT, EXT = WI::EXT, NW = WI::NW, NBLK = WI::NBLK, ND = WI::ND;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int item = blockIdx.x * (LK_THREADS / 64) + wave;
   if (item >= n_items) return;
   const int bh = item / chunks_per_row;
-  const int w1 = (item - bh * chunks_per_row) * 64 + lane;
+  const int c0 = (item - bh * chunks_per_row) * 64;
+  const int w1 = c0 + lane;
   if (w1 >= lay.W1) return;
   const int b = bh / lay.H, h = bh - b * lay.H;
   const int64_t HW = (int64_t)lay.H * lay.W1;
-  const int64_t bstride = (int64_t)lay.pitch * RB;
+  const uint32_t blk_bytes = (uint32_t)lay.pitch * 16u;
 
-  const float x = coords[((int64_t)b * coords_channels) * HW + (int64_t)h * lay.W1 + w1];
-  const float* gp = gout + ((int64_t)b * lay.L * NT) * HW + (int64_t)h * lay.W1 + w1;
+  const float x = (coords + uniform(((int64_t)b * coords_channels) * HW + (int64_t)h * lay.W1 + c0))[lane];
+  const int64_t g_u = ((int64_t)b * lay.L * NT) * HW + (int64_t)h * lay.W1 + c0;  // wave-uniform
 
-  float inv = 1.0f;
   for (int i = 0; i < lay.L; ++i) {
-    const int Wi = lay.width[i], WiP = lay.widthp[i];
-    const int qm = (w1 >> i) % WiP;
-    float* col = gvol + lay.offset[i] + ((int64_t)bh * (WiP / RB) * lay.pitch + w1) * RB;
-    const float xi = x * inv;
-    inv *= 0.5f;
+    const int Wi = lay.width[i], nb = lay.widthp[i] >> LG;
+    const float xi = x * (1.0f / (float)(1 << i));
     const float xf = floorf(xi);
     const float a = xi - xf;
-    const int base = rc_safe_int(xf) - R;
+    const win_pos pos = locate_window<RB, LG, NW>(rc_safe_int(xf) - R - EXT, w1, i, Wi, nb, lay.bias[i]);
+    char* lvl = reinterpret_cast<char*>(gvol) +
+                uniform(lay.offset[i] * (int64_t)sizeof(float) + (int64_t)bh * nb * blk_bytes);
+    const bool tiny = nb < NBLK;
 
     float g[NT];
 #pragma unroll
-    for (int k = 0; k < NT; ++k) g[k] = gp[((int64_t)i * NT + k) * HW];
+    for (int k = 0; k < NT; ++k) g[k] = (gout + uniform(g_u + ((int64_t)i * NT + k) * HW))[lane];
 
+    // the blocks of the window: block k holds group g0 + k; `own[k]` = the group exists and this
+    // lane's window reaches it
+    uint32_t off[NBLK];
+    bool own[NBLK];
+    float4 q[NBLK];
+#pragma unroll
+    for (int k = 0; k < NBLK; ++k) {
+      const int gk = pos.g0 + k;
+      own[k] = pos.any_ok && k <= pos.nbk && gk >= 0 && gk < nb;
+      const uint32_t sb = row_step(pos.sb0, (uint32_t)(own[k] ? k : 0), (uint32_t)nb, tiny);
+      off[k] = __umul24(sb, blk_bytes) + (uint32_t)w1 * 16u;
+      q[k] = *reinterpret_cast<const float4*>(lvl + off[k]);
+    }
+
+    // t[m] = gradient of window entry m (w2 = wbase + m)
     float t[ND];
 #pragma unroll
-    for (int j = 0; j < ND; ++j) t[j] = 0.f;
-
-    if (MODE == RC_COORD_EXACT) {
+    for (int m = 0; m < ND; ++m) t[m] = 0.f;
+    if constexpr (MODE == RC_COORD_EXACT) {
       const float bw = 1.0f - a;
 #pragma unroll
       for (int k = 0; k < NT; ++k) {
@@ -273,97 +298,99 @@ __global__ __launch_bounds__(LK_THREADS) void lookup_bwd_kernel(const float* __r
       }
     } else {
       const float wm1 = (float)(Wi - 1);
+      int dlt[NT];
+      float w0[NT], w1w[NT];
+      bool odd = false;
 #pragma unroll
       for (int k = 0; k < NT; ++k) {
-        int i0;
-        float w0, w1w;
-        rc_gridsample_coords(xi, k - R, wm1, &i0, &w0, &w1w);
-        if (i0 == base + k) {
-          t[k] += g[k] * w0;
-          t[k + 1] += g[k] * w1w;
-        } else {
-          // rare: this tap landed on a neighbouring integer; update its two cells directly
-          const int wa = i0, wb = i0 + 1;
-          if ((unsigned)wa < (unsigned)Wi) {
-            const int s = rc_pmod(wa - qm - RC_SKEW, WiP);
-            col[(int64_t)(s / RB) * bstride + (s % RB)] += g[k] * w0;
-          }
-          if ((unsigned)wb < (unsigned)Wi) {
-            const int s = rc_pmod(wb - qm - RC_SKEW, WiP);
-            col[(int64_t)(s / RB) * bstride + (s % RB)] += g[k] * w1w;
-          }
+        int i0k;
+        rc_gridsample_coords(xi, k - R, wm1, &i0k, &w0[k], &w1w[k]);
+        dlt[k] = i0k - (pos.wbase + EXT + k);
+        odd |= (dlt[k] != 0);
+      }
+      if (__builtin_expect(__any(odd), 0)) {
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+          const float a0 = g[k] * w0[k], a1 = g[k] * w1w[k];
+          t[k] += dlt[k] < 0 ? a0 : 0.f;
+          t[k + 1] += dlt[k] < 0 ? a1 : (dlt[k] == 0 ? a0 : 0.f);
+          t[k + 2] += dlt[k] == 0 ? a1 : (dlt[k] > 0 ? a0 : 0.f);
+          t[k + 3] += dlt[k] > 0 ? a1 : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+          t[k + EXT] += g[k] * w0[k];
+          t[k + EXT + 1] += g[k] * w1w[k];
         }
       }
     }
 #pragma unroll
-    for (int j = 0; j <= NT; ++j) t[j] = ((unsigned)(base + j) < (unsigned)Wi) ? t[j] : 0.f;
+    for (int m = 0; m < NW; ++m) t[m] = ((unsigned)(pos.wbase + m) < (unsigned)Wi) ? t[m] : 0.f;
 
-    const bool any_ok = (base + NT >= 0) && (base < Wi);
-    if (!any_ok) continue;
-    const int s0 = rc_pmod(base - qm - RC_SKEW, WiP);
-    if (s0 + NT < WiP) {
-      const int blk0 = s0 / RB, o = s0 - blk0 * RB;
-      // move tap j to slot o + j
+    // move window entry m to slot o + m of the blocks
+    {
+      const bool s1 = (pos.o & 1) != 0, s2 = (pos.o & 2) != 0;
 #pragma unroll
-      for (int m = ND - 1; m >= 1; --m) t[m] = (o & 1) ? t[m - 1] : t[m];
-      t[0] = (o & 1) ? 0.f : t[0];
-#pragma unroll
-      for (int m = ND - 1; m >= 2; --m) t[m] = (o & 2) ? t[m - 2] : t[m];
-      t[1] = (o & 2) ? 0.f : t[1];
-      t[0] = (o & 2) ? 0.f : t[0];
-      float4* p = reinterpret_cast<float4*>(col + (int64_t)blk0 * bstride);
-      const int64_t bs16 = bstride / 4;
-#pragma unroll
-      for (int k = 0; k < NBLK; ++k) {
-        if (k * RB <= o + NT) {
-          float4 q = p[k * bs16];
-          q.x += t[4 * k + 0];
-          q.y += t[4 * k + 1];
-          q.z += t[4 * k + 2];
-          q.w += t[4 * k + 3];
-          p[k * bs16] = q;
-        }
+      for (int m = ND - 1; m >= 1; --m) {
+        const float lo = t[m - 1], hi = t[m];
+        t[m] = s1 ? lo : hi;
       }
-    } else {
+      t[0] = s1 ? 0.f : t[0];
 #pragma unroll
-      for (int j = 0; j <= NT; ++j) {
-        if ((unsigned)(base + j) < (unsigned)Wi) {
-          const int s = (s0 + j) % WiP;
-          col[(int64_t)(s / RB) * bstride + (s % RB)] += t[j];
-        }
+      for (int m = ND - 1; m >= 2; --m) {
+        const float lo = t[m - 2], hi = t[m];
+        t[m] = s2 ? lo : hi;
+      }
+      t[1] = s2 ? 0.f : t[1];
+      t[0] = s2 ? 0.f : t[0];
+    }
+#pragma unroll
+    for (int k = 0; k < NBLK; ++k) {
+      if (own[k]) {
+        float4 r = q[k];
+        r.x += t[4 * k + 0];
+        r.y += t[4 * k + 1];
+        r.z += t[4 * k + 2];
+        r.w += t[4 * k + 3];
+        *reinterpret_cast<float4*>(lvl + off[k]) = r;
       }
     }
   }
 }
 
-// bias[i]: the smallest multiple of widthp[i] with base - (w1 >> i) - RC_SKEW + bias >= 0 for every
-// in-range window (base >= -(2r+1))
-void set_skew_bias(rc_dev_layout& d, int radius) {
+// bias[i]: the smallest multiple of the level's block-row count that keeps
+// g0 - (w1 >> i) / RB + nb - RC_WRAP_ROWS / RB non-negative for every window that overlaps the image
+void set_row_bias(rc_dev_layout& d, int rb, int nw) {
   for (int i = 0; i < d.L; ++i) {
-    const int lo = (2 * radius + 1) + ((d.W1 - 1) >> i) + RC_SKEW;
-    d.bias[i] = (lo + d.widthp[i] - 1) / d.widthp[i] * d.widthp[i];
+    const int nb = d.widthp[i] / rb;
+    const int gneg = (nw - 1 + rb - 1) / rb;  // -(lowest group index of an overlapping window)
+    const int lo = gneg + (((d.W1 - 1) >> i) / rb) + RC_WRAP_ROWS / rb - nb;
+    d.bias[i] = lo > 0 ? (lo + nb - 1) / nb * nb : 0;
   }
+}
+
+template <typename VT, int R, int MODE>
+int launch_fwd_mode(const void* vol, rc_dev_layout d, const float* coords, int cc, float* out, hipStream_t st) {
+  using WI = win_info<vt_info<VT>::RB, R, MODE>;
+  set_row_bias(d, vt_info<VT>::RB, WI::NW);
+  const int chunks = (d.W1 + 63) / 64;
+  const int n_items = (int)((int64_t)d.B * d.H * chunks);
+  const int blocks = (n_items + (LK_THREADS / 64) - 1) / (LK_THREADS / 64);
+  if (R == 4 && d.L == 4)  // the model's configuration: all levels' loads in flight together
+    hipLaunchKernelGGL((lookup_fwd_kernel<VT, R, MODE, (R == 4 ? 4 : 0)>), dim3(blocks), dim3(LK_THREADS), 0, st,
+                       (const VT*)vol, d, coords, cc, out, chunks, n_items);
+  else
+    hipLaunchKernelGGL((lookup_fwd_kernel<VT, R, MODE, 0>), dim3(blocks), dim3(LK_THREADS), 0, st, (const VT*)vol,
+                       d, coords, cc, out, chunks, n_items);
+  return rc_check_launch("rc_lookup_fwd");
 }
 
 template <typename VT, int R>
-int launch_fwd(const void* vol, const rc_dev_layout& d_in, const float* coords, int cc, float* out,
-               int mode, hipStream_t st) {
-  rc_dev_layout d = d_in;
-  set_skew_bias(d, R);
-  const int chunks = (d.W1 + 63) / 64;
-  const int64_t items64 = (int64_t)d.B * d.H * chunks;
-  const int n_items = (int)items64;
-  const int blocks = (n_items + (LK_THREADS / 64) - 1) / (LK_THREADS / 64);
-#define RC_LAUNCH(MODE, LV)                                                                                \
-  hipLaunchKernelGGL((lookup_fwd_kernel<VT, R, MODE, LV>), dim3(blocks), dim3(LK_THREADS), 0, st, (const VT*)vol, \
-                     d, coords, cc, out, chunks, n_items)
-  if (R == 4 && d.L == 4) {  // the model's configuration: all levels' loads in flight together
-    if (mode == RC_COORD_EXACT) RC_LAUNCH(RC_COORD_EXACT, 4); else RC_LAUNCH(RC_COORD_GRIDSAMPLE, 4);
-  } else {
-    if (mode == RC_COORD_EXACT) RC_LAUNCH(RC_COORD_EXACT, 0); else RC_LAUNCH(RC_COORD_GRIDSAMPLE, 0);
-  }
-#undef RC_LAUNCH
-  return rc_check_launch("rc_lookup_fwd");
+int launch_fwd(const void* vol, const rc_dev_layout& d, const float* coords, int cc, float* out, int mode,
+               hipStream_t st) {
+  return mode == RC_COORD_EXACT ? launch_fwd_mode<VT, R, RC_COORD_EXACT>(vol, d, coords, cc, out, st)
+                                : launch_fwd_mode<VT, R, RC_COORD_GRIDSAMPLE>(vol, d, coords, cc, out, st);
 }
 
 template <typename VT>
@@ -383,19 +410,23 @@ int dispatch_fwd_radius(const void* vol, const rc_dev_layout& d, const float* co
   return RC_EUNSUPPORTED;
 }
 
-template <int R>
-int launch_bwd(const float* coords, int cc, const float* gout, float* gvol, const rc_dev_layout& d,
-               int mode, hipStream_t st) {
+template <int R, int MODE>
+int launch_bwd_mode(const float* coords, int cc, const float* gout, float* gvol, rc_dev_layout d, hipStream_t st) {
+  using WI = win_info<4, R, MODE>;
+  set_row_bias(d, 4, WI::NW);
   const int chunks = (d.W1 + 63) / 64;
   const int n_items = (int)((int64_t)d.B * d.H * chunks);
   const int blocks = (n_items + (LK_THREADS / 64) - 1) / (LK_THREADS / 64);
-  if (mode == RC_COORD_EXACT)
-    hipLaunchKernelGGL((lookup_bwd_kernel<R, RC_COORD_EXACT>), dim3(blocks), dim3(LK_THREADS), 0, st, coords,
-                       cc, gout, gvol, d, chunks, n_items);
-  else
-    hipLaunchKernelGGL((lookup_bwd_kernel<R, RC_COORD_GRIDSAMPLE>), dim3(blocks), dim3(LK_THREADS), 0, st,
-                       coords, cc, gout, gvol, d, chunks, n_items);
+  hipLaunchKernelGGL((lookup_bwd_kernel<R, MODE>), dim3(blocks), dim3(LK_THREADS), 0, st, coords, cc, gout, gvol,
+                     d, chunks, n_items);
   return rc_check_launch("rc_lookup_bwd");
+}
+
+template <int R>
+int launch_bwd(const float* coords, int cc, const float* gout, float* gvol, const rc_dev_layout& d,
+               int mode, hipStream_t st) {
+  return mode == RC_COORD_EXACT ? launch_bwd_mode<R, RC_COORD_EXACT>(coords, cc, gout, gvol, d, st)
+                                : launch_bwd_mode<R, RC_COORD_GRIDSAMPLE>(coords, cc, gout, gvol, d, st);
 }
 
 int check_common(const rc_layout* lay, const void* a, const void* b, const void* c, int cc, int radius,
@@ -412,8 +443,8 @@ int check_common(const rc_layout* lay, const void* a, const void* b, const void*
                "grid_sample coordinates need every level at least 2 wide (W2=%lld, L=%d)",
                (long long)lay->W2, lay->L);
   RC_REQUIRE((int64_t)lay->B * lay->H * ((lay->W1 + 63) / 64) < (1ll << 31), RC_EINVAL, "too many pixels");
-  RC_REQUIRE((int64_t)(lay->widthp[0] / lay->rb + 1) * lay->pitch * 16 < (1ll << 31), RC_EINVAL,
-             "one image row of the pyramid exceeds the 32-bit lane offset range");
+  RC_REQUIRE(lay->pitch < (1 << 20) && (int64_t)(lay->widthp[0] / lay->rb + 1) * lay->pitch * 16 < (1ll << 31),
+             RC_EINVAL, "one image row of the pyramid exceeds the 32-bit lane offset range");
   RC_REQUIRE((uintptr_t)a % 16 == 0, RC_EINVAL, "pyramid pointer must be 16-byte aligned");
   return RC_OK;
 }

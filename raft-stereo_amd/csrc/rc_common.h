@@ -43,7 +43,11 @@ template <typename T> __device__ __forceinline__ float rc_round_as(float v) {
 }
 
 // ---------------------------------------------------------------- pyramid layout on device
-constexpr int RC_SKEW = 17;  // s = (w2 - (w1 >> i) - RC_SKEW) mod widthp  (see rc_layout)
+// A pixel's column of level i is cut into groups of RB = 16 / sizeof(element) consecutive w2
+// (one 16-byte block each).  Group g of pixel position q = w1 >> i is stored in block row
+//     sb = (g - (q / RB) + NB - RC_WRAP_ROWS / RB) mod NB,      NB = widthp / RB,
+// so the wrap-around of a column sits at disparities of about -RC_WRAP_ROWS level-i pixels.
+constexpr int RC_WRAP_ROWS = 32;
 
 struct rc_dev_layout {
   int32_t L;
@@ -52,7 +56,7 @@ struct rc_dev_layout {
   int32_t B;
   int32_t width[RC_MAX_LEVELS];
   int32_t widthp[RC_MAX_LEVELS];
-  int32_t bias[RC_MAX_LEVELS];  // lookup only: multiple of widthp that makes every skew argument >= 0
+  int32_t bias[RC_MAX_LEVELS];  // lookup only (set by its launcher): keeps the block-row argument >= 0
   int64_t offset[RC_MAX_LEVELS];
 };
 
@@ -82,11 +86,19 @@ __device__ __forceinline__ int rc_pmod(int a, int m) {
   return r < 0 ? r + m : r;
 }
 
-// Element offset of skew row s, pixel w1 inside the level-`i` slab of image row `bh`
-// (RB = rows per 16-byte block = 16 / sizeof(element)).
+// Block row of group g for pixel position q (both already divided down to level i); nb = block rows.
 template <int RB>
-__device__ __forceinline__ int64_t rc_cell(const rc_dev_layout& lay, int i, int64_t bh, int s, int w1) {
-  return lay.offset[i] + ((bh * (lay.widthp[i] / RB) + s / RB) * lay.pitch + w1) * RB + (s % RB);
+__host__ __device__ __forceinline__ int rc_block_row(int g, int q, int nb) {
+  int r = (g - q / RB + nb - RC_WRAP_ROWS / RB) % nb;
+  return r < 0 ? r + nb : r;
+}
+
+// Element offset of (row bh, pixel w1, level-i column w2i) (RB = elements per 16-byte block).
+template <int RB>
+__device__ __forceinline__ int64_t rc_cell(const rc_dev_layout& lay, int i, int64_t bh, int w1, int w2i) {
+  const int nb = lay.widthp[i] / RB;
+  const int sb = rc_block_row<RB>(w2i / RB, w1 >> i, nb);
+  return lay.offset[i] + ((bh * nb + sb) * lay.pitch + w1) * RB + (w2i % RB);
 }
 
 // float -> int that maps nan / huge values to a far-out-of-range index (all taps zero)

@@ -56,21 +56,25 @@ def test_null_and_bad_arguments_are_rejected_without_a_gpu():
     assert b"rc_pyramid_layout" in lib.rc_last_error_string()
 
 
-def test_skew_index_is_a_bijection():
-    """Every (w1, w2) of a level maps to its own cell of the blocked-skew layout, and for a
-    fixed pixel consecutive w2 are consecutive skew rows (modulo the padded width)."""
-    from raft_stereo_amd._lib import RC_SKEW
+def test_block_row_index_is_a_bijection():
+    """Every (w1, w2) of a level maps to its own cell of the group-skewed layout, a group of rb
+    consecutive w2 is one 16-byte block, and for a fixed pixel consecutive groups are consecutive
+    block rows (modulo the number of block rows)."""
+    from raft_stereo_amd._lib import RC_WRAP_ROWS
     for W1, W2, i, rb in [(40, 45, 0, 8), (40, 45, 2, 4), (72, 200, 3, 8), (200, 45, 1, 4), (33, 33, 1, 8)]:
         Wi = W2 >> i
         WiP = (Wi + 7) // 8 * 8
+        nb = WiP // rb
         pitch = (W1 + 63) // 64 * 64
         w1 = np.arange(W1)[:, None]
         w2 = np.arange(Wi)[None, :]
-        s = (w2 - (w1 >> i) - RC_SKEW) % WiP
-        cell = ((s // rb) * pitch + w1) * rb + s % rb
+        sb = (w2 // rb - (w1 >> i) // rb + nb - RC_WRAP_ROWS // rb) % nb
+        cell = (sb * pitch + w1) * rb + w2 % rb
         assert len(set(cell.ravel().tolist())) == W1 * Wi
         assert cell.max() < WiP * pitch
-        assert np.all((s[:, 1:] - s[:, :-1]) % WiP == 1)
+        assert np.all(cell[:, 1:][:, (w2[0, 1:] % rb) != 0] - cell[:, :-1][:, (w2[0, 1:] % rb) != 0] == 1)
+        nxt = (w2[0, 1:] % rb) == 0                       # first element of the next group
+        assert np.all((sb[:, 1:][:, nxt] - sb[:, :-1][:, nxt]) % nb == 1 % nb)
 
 
 def test_dispatch_and_shards():
