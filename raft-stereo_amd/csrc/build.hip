@@ -30,6 +30,7 @@ typedef short s8v __attribute__((ext_vector_type(8)));
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 typedef __bf16 b8v __attribute__((ext_vector_type(8)));
 typedef float f4v __attribute__((ext_vector_type(4)));
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 
 template <typename T> __device__ __forceinline__ f4v mfma16(s8v a, s8v b, f4v c);
 template <> __device__ __forceinline__ f4v mfma16<rc_half>(s8v a, s8v b, f4v c) {
@@ -51,40 +52,49 @@ template <typename T> struct build_cfg {
   static constexpr int LDS_BYTES = KMAX * PF * ESZ;
 };
 
-// ---- staging: one [K][128-byte] tile, global -> registers (8 x 16 B per thread) -> LDS
-template <typename T>
-__device__ __forceinline__ void stage_load(uint4 (&regs)[8], const T* __restrict__ rowbase, int64_t kstride,
-                                           int W, int n0, int D, bool vec) {
+// ---- staging: one [K][128-byte] tile, global -> registers (8 x 16 B per thread) -> LDS.
+// FAST (rows 16-byte aligned, width a multiple of the segment, D == KMAX): no branch and no
+// zero fill, so the 8 loads issue back to back off one scalar base: segments past the end of the
+// row re-read its last segment, and what they produce only ever lands in padding cells of the
+// pyramid (w2 >= W2) or in columns that are not stored (w1 >= W1).
+template <typename T, bool FAST>
+__device__ __forceinline__ void stage_load(u4v (&regs)[8], const T* __restrict__ rowbase, int64_t kstride,
+                                           int W, int n0, int D) {
   constexpr int EPS = 16 / sizeof(T);
   const int seg = threadIdx.x & 7, kr = threadIdx.x >> 3;
   const int col = n0 + seg * EPS;
+  if constexpr (FAST) {
+    const uint32_t voff = ((uint32_t)kr * (uint32_t)kstride + (uint32_t)min(col, W - EPS)) * (uint32_t)sizeof(T);
 #pragma unroll
-  for (int p = 0; p < 8; ++p) {
-    const int k = p * 32 + kr;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (k < D) {
-      const T* src = rowbase + (int64_t)k * kstride + col;
-      if (vec) {
-        if (col < W) v = *reinterpret_cast<const uint4*>(src);
-      } else {
+    for (int p = 0; p < 8; ++p) {
+      const char* src = reinterpret_cast<const char*>(rowbase) + (int64_t)p * 32 * kstride * (int64_t)sizeof(T);
+      regs[p] = *reinterpret_cast<const u4v*>(src + voff);
+    }
+  } else {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int k = p * 32 + kr;
+      u4v v = (u4v)(0u);
+      if (k < D) {
+        const T* src = rowbase + (int64_t)k * kstride + col;
         alignas(16) T tmp[EPS];
 #pragma unroll
         for (int e = 0; e < EPS; ++e) tmp[e] = (col + e < W) ? src[e] : (T)0.0f;
-        v = *reinterpret_cast<uint4*>(tmp);
+        v = *reinterpret_cast<u4v*>(tmp);
       }
+      regs[p] = v;
     }
-    regs[p] = v;
   }
 }
 
 template <typename T, int PF>
-__device__ __forceinline__ void stage_store(const uint4 (&regs)[8], T* ldsF) {
+__device__ __forceinline__ void stage_store(const u4v (&regs)[8], T* ldsF) {
   constexpr int EPS = 16 / sizeof(T);
   const int seg = threadIdx.x & 7, kr = threadIdx.x >> 3;
 #pragma unroll
   for (int p = 0; p < 8; ++p) {
     const int k = p * 32 + kr;
-    *reinterpret_cast<uint4*>(ldsF + k * PF + seg * EPS) = regs[p];
+    *reinterpret_cast<u4v*>(ldsF + k * PF + seg * EPS) = regs[p];
   }
 }
 
@@ -124,11 +134,12 @@ __device__ __forceinline__ void transpose_rows(uint32_t (&r)[4]) {
   swap32(r[1], r[3]);
 }
 
-template <typename VT> __device__ __forceinline__ uint32_t bits16(float v) {
-  return (uint32_t)__builtin_bit_cast(uint16_t, rc_from_float<VT>(v));
-}
+typedef float f2v __attribute__((ext_vector_type(2)));
+// two floats -> one dword of two 16-bit values (v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32, round to nearest even)
 template <typename VT> __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
-  return bits16<VT>(lo) | (bits16<VT>(hi) << 16);
+  typedef VT v2 __attribute__((ext_vector_type(2)));
+  const f2v f = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, v2));
 }
 template <typename VT> __device__ __forceinline__ float unpack_lo(uint32_t d) {
   return rc_to_float(__builtin_bit_cast(VT, (uint16_t)(d & 0xffffu)));
@@ -136,36 +147,38 @@ template <typename VT> __device__ __forceinline__ float unpack_lo(uint32_t d) {
 template <typename VT> __device__ __forceinline__ float unpack_hi(uint32_t d) {
   return rc_to_float(__builtin_bit_cast(VT, (uint16_t)(d >> 16)));
 }
+template <> __device__ __forceinline__ float unpack_lo<rc_bf16>(uint32_t d) { return __uint_as_float(d << 16); }
+template <> __device__ __forceinline__ float unpack_hi<rc_bf16>(uint32_t d) { return __uint_as_float(d & 0xffff0000u); }
 
-// Where a wave's blocks go: level bases of this image row, and the block-row arithmetic
+// Where a wave's blocks go.  Per level: a wave-uniform base (this image row's slab) plus a 32-bit
+// lane offset (block row * pitch + pixel) * 16 bytes.
 template <typename VT> struct out_map {
   static constexpr int RB = 16 / (int)sizeof(VT);
   static constexpr int LG = sizeof(VT) == 4 ? 2 : 3;
-  char* vol;
-  const rc_dev_layout* lay;
-  int64_t row;
+  char* base[RC_MAX_LEVELS];     // wave-uniform
+  uint32_t nb[RC_MAX_LEVELS];    // block rows
+  uint32_t kb[RC_MAX_LEVELS];    // bias - RC_WRAP_ROWS / RB
+  bool slowmod[RC_MAX_LEVELS];   // level only a few pixels wide: general modulus
+  uint32_t blk_bytes;            // pitch * 16
   int W1;
 
-  // byte address of the block of group G of pixel `col` at level i
-  __device__ __forceinline__ char* block(int i, int col, int G) const {
-    const uint32_t nb = (uint32_t)(lay->widthp[i] >> LG), bias = (uint32_t)lay->bias[i];
-    uint32_t t = (uint32_t)(G - ((col >> i) >> LG) - RC_WRAP_ROWS / RB) + bias;  // >= 0 by choice of bias
-    if (bias <= 3 * nb) {  // wave-uniform; always, unless the level is only a few pixels wide
-      t = min(t, t - 2 * nb);
-      t = min(t, t - nb);
+  // byte offset of the block of group G of pixel `col` at level i
+  __device__ __forceinline__ uint32_t offset(int i, int col, int G) const {
+    uint32_t t = (uint32_t)(G - ((col >> i) >> LG)) + kb[i];  // >= 0 by choice of bias
+    if (!slowmod[i]) {  // wave-uniform
+      t = min(t, t - 2 * nb[i]);
+      t = min(t, t - nb[i]);
     } else {
-      t %= nb;
+      t %= nb[i];
     }
-    return vol + (lay->offset[i] + ((row * nb + t) * lay->pitch + col) * RB) * (int64_t)sizeof(VT);
+    return __umul24(t, blk_bytes) + (uint32_t)col * 16u;
   }
-  __device__ __forceinline__ bool ok(int i, int col, int G) const {
-    return col < W1 && G < (lay->widthp[i] >> LG);
-  }
+  __device__ __forceinline__ bool ok(int i, int col, int G) const { return col < W1 && (uint32_t)G < nb[i]; }
   __device__ __forceinline__ void store16(int i, int col, int G, uint32_t a, uint32_t b, uint32_t c, uint32_t d) const {
-    if (ok(i, col, G)) *reinterpret_cast<uint4*>(block(i, col, G)) = make_uint4(a, b, c, d);
+    if (ok(i, col, G)) *reinterpret_cast<uint4*>(base[i] + offset(i, col, G)) = make_uint4(a, b, c, d);
   }
   __device__ __forceinline__ void store8(int i, int col, int G, int half, uint32_t a, uint32_t b) const {
-    if (ok(i, col, G)) *reinterpret_cast<uint2*>(block(i, col, G) + 8 * half) = make_uint2(a, b);
+    if (ok(i, col, G)) *reinterpret_cast<uint2*>(base[i] + (offset(i, col, G) + 8u * half)) = make_uint2(a, b);
   }
 };
 
@@ -177,19 +190,16 @@ __device__ __forceinline__ void epilogue16(const f4v (&acc)[4][2], float scale, 
                                            int n0, int cw) {
   const int lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
   const int col_sw = cw + 16 * (g & 1) + li;  // column a lane serves after a swap16 between the column tiles
-  float p1[4][2][2];
+  uint32_t q1[4][2];  // level 1: two values per (row tile, column tile)
 #pragma unroll
   for (int rt = 0; rt < 4; ++rt) {
     uint32_t x[2][2];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
-      float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = rc_round_as<VT>(acc[rt][ct][r] * scale);
-      x[ct][0] = pack2<VT>(v[0], v[1]);
-      x[ct][1] = pack2<VT>(v[2], v[3]);
-      p1[rt][ct][0] = rc_round_as<VT>(0.5f * (v[0] + v[1]));
-      p1[rt][ct][1] = rc_round_as<VT>(0.5f * (v[2] + v[3]));
+      x[ct][0] = pack2<VT>(acc[rt][ct][0] * scale, acc[rt][ct][1] * scale);
+      x[ct][1] = pack2<VT>(acc[rt][ct][2] * scale, acc[rt][ct][3] * scale);
+      q1[rt][ct] = pack2<VT>(0.5f * (unpack_lo<VT>(x[ct][0]) + unpack_hi<VT>(x[ct][0])),
+                             0.5f * (unpack_lo<VT>(x[ct][1]) + unpack_hi<VT>(x[ct][1])));
     }
     // lane rows 0,2 collect the 8-row blocks of column tile 0, lane rows 1,3 those of column tile 1
     swap16(x[0][0], x[1][0]);
@@ -203,8 +213,8 @@ __device__ __forceinline__ void epilogue16(const f4v (&acc)[4][2], float scale, 
     uint32_t q[4];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
-      q[rt] = pack2<VT>(p1[rt][ct][0], p1[rt][ct][1]);
-      p2[rt][ct] = rc_round_as<VT>(0.5f * (p1[rt][ct][0] + p1[rt][ct][1]));
+      q[rt] = q1[rt][ct];
+      p2[rt][ct] = 0.5f * (unpack_lo<VT>(q[rt]) + unpack_hi<VT>(q[rt]));
     }
     transpose_rows(q);  // lane row g: the level-1 block of row tile g
     om.store16(1, cw + 16 * ct + li, (n0 >> 4) + g, q[0], q[1], q[2], q[3]);
@@ -218,11 +228,9 @@ __device__ __forceinline__ void epilogue16(const f4v (&acc)[4][2], float scale, 
   const uint32_t d2 = __builtin_amdgcn_perm(w[1], w[0], 0x07060302u), d3 = __builtin_amdgcn_perm(w[3], w[2], 0x07060302u);
   om.store16(2, col_sw, (n0 >> 5) + (g >> 1), d0, d1, d2, d3);
   if (L < 4) return;
-  const float q0 = rc_round_as<VT>(0.5f * (unpack_lo<VT>(d0) + unpack_hi<VT>(d0)));
-  const float q1 = rc_round_as<VT>(0.5f * (unpack_lo<VT>(d1) + unpack_hi<VT>(d1)));
-  const float q2 = rc_round_as<VT>(0.5f * (unpack_lo<VT>(d2) + unpack_hi<VT>(d2)));
-  const float q3 = rc_round_as<VT>(0.5f * (unpack_lo<VT>(d3) + unpack_hi<VT>(d3)));
-  om.store8(3, col_sw, n0 >> 6, g >> 1, pack2<VT>(q0, q1), pack2<VT>(q2, q3));
+  const float e0 = 0.5f * (unpack_lo<VT>(d0) + unpack_hi<VT>(d0)), e1 = 0.5f * (unpack_lo<VT>(d1) + unpack_hi<VT>(d1));
+  const float e2 = 0.5f * (unpack_lo<VT>(d2) + unpack_hi<VT>(d2)), e3 = 0.5f * (unpack_lo<VT>(d3) + unpack_hi<VT>(d3));
+  om.store8(3, col_sw, n0 >> 6, g >> 1, pack2<VT>(e0, e1), pack2<VT>(e2, e3));
 }
 
 // ---- epilogue, f32 pyramid: a 32 (w2) x 32 (w1) wave tile (two row tiles), n0 a multiple of 32.
@@ -269,10 +277,10 @@ __device__ __forceinline__ void epilogue32(const f4v& a00, const f4v& a01, const
   om.store8(3, col_sw, n0 >> 5, g >> 1, __float_as_uint(q0), __float_as_uint(q1));
 }
 
-template <typename T, typename VT>
+template <typename T, typename VT, bool FAST>
 __global__ __launch_bounds__(BT) void build_kernel(const T* __restrict__ f1, const T* __restrict__ f2,
                                                    VT* __restrict__ vol, rc_dev_layout lay, int D, float scale,
-                                                   int n_tiles, int n_rows, bool vec1, bool vec2) {
+                                                   int n_tiles, int n_rows) {
   using C = build_cfg<T>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* ldsF = reinterpret_cast<T*>(smem);
@@ -291,13 +299,13 @@ __global__ __launch_bounds__(BT) void build_kernel(const T* __restrict__ f1, con
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, li = lane & 15;
   const int cw = c0 + wave * TW;  // first w1 column of this wave
-  const int nk = (D + C::KSTEP - 1) / C::KSTEP;
+  const int nk = FAST ? C::NKS : (D + C::KSTEP - 1) / C::KSTEP;  // FAST: D == KMAX, loops fully unrolled
 
   const T* f1row = f1 + ((int64_t)b * D * lay.H + h) * W1;
   const T* f2row = f2 + ((int64_t)b * D * lay.H + h) * W2;
   const int64_t ks1 = (int64_t)lay.H * W1, ks2 = (int64_t)lay.H * W2;
 
-  uint4 regs[8];
+  u4v regs[8];
 
   // ---- f1 tile -> per-wave register-resident B operand
   s8v bfrag16[C::IS16 ? C::NKS : 1][2];
@@ -306,7 +314,7 @@ __global__ __launch_bounds__(BT) void build_kernel(const T* __restrict__ f1, con
     // the 128 columns pass through the staging tile in two halves of 64
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-      stage_load<T>(regs, f1row, ks1, W1, c0 + 64 * half, D, vec1);
+      stage_load<T, FAST>(regs, f1row, ks1, W1, c0 + 64 * half, D);
       if (half) __syncthreads();  // the first half's fragments have been read
       stage_store<T, C::PF>(regs, ldsF);
       __syncthreads();
@@ -323,9 +331,9 @@ __global__ __launch_bounds__(BT) void build_kernel(const T* __restrict__ f1, con
         }
       }
     }
-    stage_load<T>(regs, f2row, ks2, W2, 0, D, vec2);  // chunk 0 of f2, in flight
+    stage_load<T, FAST>(regs, f2row, ks2, W2, 0, D);  // chunk 0 of f2, in flight
   } else {
-    stage_load<T>(regs, f2row, ks2, W2, 0, D, vec2);
+    stage_load<T, FAST>(regs, f2row, ks2, W2, 0, D);
 #pragma unroll
     for (int ks = 0; ks < C::NKS; ++ks) {
 #pragma unroll
@@ -337,10 +345,17 @@ __global__ __launch_bounds__(BT) void build_kernel(const T* __restrict__ f1, con
   }
 
   out_map<VT> om;
-  om.vol = reinterpret_cast<char*>(vol);
-  om.lay = &lay;
-  om.row = row;
+  om.blk_bytes = (uint32_t)lay.pitch * 16u;
   om.W1 = W1;
+#pragma unroll
+  for (int i = 0; i < RC_MAX_LEVELS; ++i) {
+    const int nb = lay.widthp[i < L ? i : 0] >> out_map<VT>::LG;
+    om.nb[i] = (uint32_t)nb;
+    om.kb[i] = (uint32_t)(lay.bias[i < L ? i : 0] - RC_WRAP_ROWS / out_map<VT>::RB);
+    om.slowmod[i] = lay.bias[i < L ? i : 0] > 3 * nb;
+    om.base[i] = reinterpret_cast<char*>(vol) +
+                 (lay.offset[i < L ? i : 0] * (int64_t)sizeof(VT) + (int64_t)row * nb * om.blk_bytes);
+  }
 
   const int n_chunks = (W2 + C::TN - 1) / C::TN;
   for (int c = 0; c < n_chunks; ++c) {
@@ -348,7 +363,7 @@ __global__ __launch_bounds__(BT) void build_kernel(const T* __restrict__ f1, con
     __syncthreads();  // previous readers of ldsF are done
     stage_store<T, C::PF>(regs, ldsF);
     __syncthreads();
-    if (c + 1 < n_chunks) stage_load<T>(regs, f2row, ks2, W2, n0 + C::TN, D, vec2);
+    if (c + 1 < n_chunks) stage_load<T, FAST>(regs, f2row, ks2, W2, n0 + C::TN, D);
 
     f4v acc[C::NRT][2];
 #pragma unroll
@@ -470,8 +485,11 @@ int launch_build(const void* f1, const void* f2, void* vol, const rc_layout* lay
     return RC_ENODEVICE;
   }
   if (!attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&build_kernel<T, VT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&build_kernel<T, VT, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&build_kernel<T, VT, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     if (e != hipSuccess) {
       rc_set_error("hipFuncSetAttribute(%d bytes LDS): %s", C::LDS_BYTES, hipGetErrorString(e));
       return (int)e;
@@ -485,10 +503,16 @@ int launch_build(const void* f1, const void* f2, void* vol, const rc_layout* lay
   const int64_t blocks = (int64_t)((n_rows + 7) / 8) * 8 * n_tiles;
   RC_REQUIRE(blocks < (1ll << 31), RC_EINVAL, "grid too large");
   constexpr int EPS = 16 / (int)sizeof(T);
-  const bool vec1 = (lay->W1 % EPS == 0) && (((uintptr_t)f1) % 16 == 0);
-  const bool vec2 = (lay->W2 % EPS == 0) && (((uintptr_t)f2) % 16 == 0);
-  hipLaunchKernelGGL((build_kernel<T, VT>), dim3((unsigned)blocks), dim3(BT), C::LDS_BYTES, st,
-                     (const T*)f1, (const T*)f2, (VT*)vol, d, D, scale, n_tiles, n_rows, vec1, vec2);
+  // the branch-free staging path: aligned rows, full depth, 32-bit byte offsets inside one image
+  const bool fast = (lay->W1 % EPS == 0) && (((uintptr_t)f1) % 16 == 0) && (lay->W2 % EPS == 0) &&
+                    (((uintptr_t)f2) % 16 == 0) && D == KMAX &&
+                    (int64_t)D * lay->H * (lay->W1 > lay->W2 ? lay->W1 : lay->W2) * (int64_t)sizeof(T) < (1ll << 31);
+  if (fast)
+    hipLaunchKernelGGL((build_kernel<T, VT, true>), dim3((unsigned)blocks), dim3(BT), C::LDS_BYTES, st,
+                       (const T*)f1, (const T*)f2, (VT*)vol, d, D, scale, n_tiles, n_rows);
+  else
+    hipLaunchKernelGGL((build_kernel<T, VT, false>), dim3((unsigned)blocks), dim3(BT), C::LDS_BYTES, st,
+                       (const T*)f1, (const T*)f2, (VT*)vol, d, D, scale, n_tiles, n_rows);
   return rc_check_launch("rc_build_pyramid");
 }
 
