@@ -53,22 +53,36 @@ template <typename T> struct build_cfg {
 };
 
 // ---- staging: one [K][128-byte] tile, global -> registers (8 x 16 B per thread) -> LDS.
-// FAST (rows 16-byte aligned, width a multiple of the segment, D == KMAX): no branch and no
-// zero fill, so the 8 loads issue back to back off one scalar base: segments past the end of the
-// row re-read its last segment, and what they produce only ever lands in padding cells of the
-// pyramid (w2 >= W2) or in columns that are not stored (w1 >= W1).
-template <typename T, bool FAST>
+// FAST > 0 (rows 4-byte aligned, D == KMAX): no zero fill and one scalar base, so the 8 loads issue
+// back to back; the 16-byte loads only assume dword alignment.  A segment wholly past the end of
+// the row re-reads the row start: what it produces only ever lands in padding cells of the pyramid
+// (w2 >= W2) or in columns that are not stored (w1 >= W1).  The one segment that straddles the
+// end of a row is read element by element.
+typedef uint32_t u4v_a4 __attribute__((ext_vector_type(4), aligned(4)));
+
+template <typename T, int FAST>
 __device__ __forceinline__ void stage_load(u4v (&regs)[8], const T* __restrict__ rowbase, int64_t kstride,
                                            int W, int n0, int D) {
   constexpr int EPS = 16 / sizeof(T);
   const int seg = threadIdx.x & 7, kr = threadIdx.x >> 3;
   const int col = n0 + seg * EPS;
   if constexpr (FAST) {
-    const uint32_t voff = ((uint32_t)kr * (uint32_t)kstride + (uint32_t)min(col, W - EPS)) * (uint32_t)sizeof(T);
+    if (FAST == 2 || col + EPS <= W || col >= W) {  // FAST == 2: W is a multiple of the segment
+      const uint32_t voff = ((uint32_t)kr * (uint32_t)kstride + (uint32_t)(col >= W ? 0 : col)) * (uint32_t)sizeof(T);
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const char* src = reinterpret_cast<const char*>(rowbase) + (int64_t)p * 32 * kstride * (int64_t)sizeof(T);
-      regs[p] = *reinterpret_cast<const u4v*>(src + voff);
+      for (int p = 0; p < 8; ++p) {
+        const char* src = reinterpret_cast<const char*>(rowbase) + (int64_t)p * 32 * kstride * (int64_t)sizeof(T);
+        regs[p] = *reinterpret_cast<const u4v_a4*>(src + voff);
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const T* src = rowbase + (int64_t)(p * 32 + kr) * kstride + col;
+        alignas(16) T tmp[EPS];
+#pragma unroll
+        for (int e = 0; e < EPS; ++e) tmp[e] = (col + e < W) ? src[e] : (T)0.0f;
+        regs[p] = *reinterpret_cast<u4v*>(tmp);
+      }
     }
   } else {
 #pragma unroll
@@ -277,7 +291,7 @@ __device__ __forceinline__ void epilogue32(const f4v& a00, const f4v& a01, const
   om.store8(3, col_sw, n0 >> 5, g >> 1, __float_as_uint(q0), __float_as_uint(q1));
 }
 
-template <typename T, typename VT, bool FAST>
+template <typename T, typename VT, int FAST>
 __global__ __launch_bounds__(BT) void build_kernel(const T* __restrict__ f1, const T* __restrict__ f2,
                                                    VT* __restrict__ vol, rc_dev_layout lay, int D, float scale,
                                                    int n_tiles, int n_rows) {
@@ -485,10 +499,13 @@ int launch_build(const void* f1, const void* f2, void* vol, const rc_layout* lay
     return RC_ENODEVICE;
   }
   if (!attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&build_kernel<T, VT, true>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&build_kernel<T, VT, 0>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&build_kernel<T, VT, false>),
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&build_kernel<T, VT, 1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&build_kernel<T, VT, 2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     if (e != hipSuccess) {
       rc_set_error("hipFuncSetAttribute(%d bytes LDS): %s", C::LDS_BYTES, hipGetErrorString(e));
@@ -503,16 +520,18 @@ int launch_build(const void* f1, const void* f2, void* vol, const rc_layout* lay
   const int64_t blocks = (int64_t)((n_rows + 7) / 8) * 8 * n_tiles;
   RC_REQUIRE(blocks < (1ll << 31), RC_EINVAL, "grid too large");
   constexpr int EPS = 16 / (int)sizeof(T);
-  // the branch-free staging path: aligned rows, full depth, 32-bit byte offsets inside one image
-  const bool fast = (lay->W1 % EPS == 0) && (((uintptr_t)f1) % 16 == 0) && (lay->W2 % EPS == 0) &&
-                    (((uintptr_t)f2) % 16 == 0) && D == KMAX &&
+  // the branch-free staging path: dword-aligned rows, full depth, 32-bit byte offsets inside one image
+  const bool fast = (lay->W1 * sizeof(T)) % 4 == 0 && ((uintptr_t)f1) % 4 == 0 && (lay->W2 * sizeof(T)) % 4 == 0 &&
+                    ((uintptr_t)f2) % 4 == 0 && lay->W1 >= EPS && lay->W2 >= EPS && D == KMAX &&
                     (int64_t)D * lay->H * (lay->W1 > lay->W2 ? lay->W1 : lay->W2) * (int64_t)sizeof(T) < (1ll << 31);
-  if (fast)
-    hipLaunchKernelGGL((build_kernel<T, VT, true>), dim3((unsigned)blocks), dim3(BT), C::LDS_BYTES, st,
-                       (const T*)f1, (const T*)f2, (VT*)vol, d, D, scale, n_tiles, n_rows);
-  else
-    hipLaunchKernelGGL((build_kernel<T, VT, false>), dim3((unsigned)blocks), dim3(BT), C::LDS_BYTES, st,
-                       (const T*)f1, (const T*)f2, (VT*)vol, d, D, scale, n_tiles, n_rows);
+  const bool whole = lay->W1 % EPS == 0 && lay->W2 % EPS == 0;  // no segment straddles the end of a row
+#define RC_LAUNCH_BUILD(F)                                                                               \
+  hipLaunchKernelGGL((build_kernel<T, VT, F>), dim3((unsigned)blocks), dim3(BT), C::LDS_BYTES, st, (const T*)f1, \
+                     (const T*)f2, (VT*)vol, d, D, scale, n_tiles, n_rows)
+  if (fast && whole) RC_LAUNCH_BUILD(2);
+  else if (fast) RC_LAUNCH_BUILD(1);
+  else RC_LAUNCH_BUILD(0);
+#undef RC_LAUNCH_BUILD
   return rc_check_launch("rc_build_pyramid");
 }
 

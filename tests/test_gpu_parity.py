@@ -106,7 +106,8 @@ def test_alt_fp32_matches_reference_reg(R, golden, case, kind):
 
 # ------------------------------------------------------------------ MFMA kernel vs the naive kernel
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("shape", [(2, 256, 3, 312, 312), (1, 96, 2, 70, 131), (1, 256, 2, 200, 45)])
+@pytest.mark.parametrize("shape", [(2, 256, 3, 312, 312), (1, 96, 2, 70, 131), (1, 256, 2, 200, 45),
+                                   (1, 256, 3, 180, 180), (1, 256, 2, 90, 150), (1, 256, 2, 752, 94)])
 def test_build_mfma_equals_naive_kernel(R, dtype, shape):
     from raft_stereo_amd._lib import lib, check
     B, D, H, W1, W2 = shape
