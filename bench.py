@@ -156,7 +156,7 @@ def cpu_baseline(cfg, budget_s=15.0):
         n += 1
         tb += b
         tl += l
-        if time.perf_counter() - t0 > budget_s or n >= 20:
+        if time.perf_counter() - t0 > budget_s or n >= 500:
             break
     per_pair = (tb + tl) / n * (cfg["H"] / sample_h)
     return dict(value=round(1.0 / per_pair, 4), unit="pairs/s", cores=used, kind="port",

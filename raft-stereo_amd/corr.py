@@ -12,6 +12,8 @@ CorrSamplerHip mirrors the autograd wrapper of core/corr.py:17-29 on top of the
 Torch only owns memory, streams and the autograd graph here; all arithmetic is in the HIP
 library.  There is no CPU or eager fallback: tensors must live on a GPU.
 """
+import ctypes
+
 import torch
 
 from raft_stereo_amd import _lib, sampler
@@ -23,6 +25,25 @@ COORD_MODES = {"exact": _lib.RC_COORD_EXACT, "gridsample": _lib.RC_COORD_GRIDSAM
 
 def _stream(dev):
     return torch.cuda.current_stream(dev).cuda_stream
+
+
+class _on_device:
+    """`with torch.cuda.device(dev)` without its cost when `dev` is already current (the per-iteration
+    lookup of a small image is bound by host time, not by the kernel)."""
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, dev):
+        self.idx = dev.index if dev.index is not None else torch.cuda.current_device()
+
+    def __enter__(self):
+        self.prev = torch.cuda.current_device()
+        if self.prev != self.idx:
+            torch.cuda.set_device(self.idx)
+
+    def __exit__(self, *exc):
+        if self.prev != self.idx:
+            torch.cuda.set_device(self.prev)
+        return False
 
 
 def _check_fmaps(fmap1, fmap2, num_levels, radius):
@@ -54,6 +75,8 @@ def _check_coords(coords, B, H, W1, device):
         raise ValueError(f"coords must be [B={B}, >=1, H={H}, W={W1}], got {tuple(coords.shape)}")
     if coords.device != device:
         raise RuntimeError("coords live on a different device than the feature maps")
+    if coords.dtype is torch.float32 and coords.is_contiguous():
+        return coords.detach() if coords.requires_grad else coords
     return coords.detach().float().contiguous()
 
 
@@ -156,15 +179,18 @@ class CorrBlock1DHip:
             check(lib.rc_build_pyramid(fmap1.data_ptr(), fmap2.data_ptr(), self.volume.data_ptr(), self.layout,
                                        self.D, self.in_dtype, _stream(self.device)),
                   "rc_build_pyramid")
+        # per-call constants of the lookup, converted once
+        self._vol_ptr = self.volume.data_ptr()
+        self._lay_ref = ctypes.byref(self.layout)
+        self._out_shape = (self.B, self.num_levels * (2 * self.radius + 1), self.H, self.W1)
 
     def _lookup(self, coords):
-        nt = 2 * self.radius + 1
-        with torch.cuda.device(self.device):
-            out = torch.empty((self.B, self.num_levels * nt, self.H, self.W1), dtype=torch.float32,
-                              device=self.device)
-            check(lib.rc_lookup_fwd(self.volume.data_ptr(), self.layout, coords.data_ptr(),
-                                    coords.shape[1], out.data_ptr(), self.radius, self.coord_mode,
-                                    _stream(self.device)), "rc_lookup_fwd")
+        with _on_device(self.device):
+            out = torch.empty(self._out_shape, dtype=torch.float32, device=self.device)
+            rc = lib.rc_lookup_fwd(self._vol_ptr, self._lay_ref, coords.data_ptr(), coords.shape[1],
+                                   out.data_ptr(), self.radius, self.coord_mode, _stream(self.device))
+            if rc:
+                check(rc, "rc_lookup_fwd")
         return out
 
     def __call__(self, coords):
