@@ -1,5 +1,5 @@
 // Experiment bench for the lookup kernel (NOT part of the library): times the product entry point
-// and stripped-down variants on a KITTI-sized f16 pyramid to see which part bounds it.
+// and plain streaming kernels with the same byte mix on a KITTI-sized f16 pyramid to see which part bounds it.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/lab_lookup tools/lab_lookup.hip \
 //         raft-stereo_amd/csrc/core.hip raft-stereo_amd/csrc/lookup.hip
 #include "../raft-stereo_amd/csrc/rc_common.h"
@@ -109,18 +109,10 @@ struct Ctx {
   int variant;
 };
 
-extern "C" int rc_lab_lookup(const void* vol, const rc_layout* lay, const float* coords, int cc, float* out,
-                             int variant, void* stream);
-
 static void launch_product(void* c_) {
   Ctx* c = (Ctx*)c_;
   int rc = rc_lookup_fwd(c->vol, &c->lay, c->coords, 2, c->out, 4, RC_COORD_EXACT, 0);
   if (rc) { fprintf(stderr, "rc_lookup_fwd: %s\n", rc_last_error_string()); exit(1); }
-}
-static void launch_lab(void* c_) {
-  Ctx* c = (Ctx*)c_;
-  int rc = rc_lab_lookup(c->vol, &c->lay, c->coords, 2, c->out, c->variant, 0);
-  if (rc) { fprintf(stderr, "rc_lab_lookup: %d\n", rc); exit(1); }
 }
 template <int NL, int NS> static void launch_stream(void* c_) {
   Ctx* c = (Ctx*)c_;
@@ -179,11 +171,5 @@ int main(int argc, char** argv) {
   report("stores: 9 x dwordx4, 4 x 256 B runs", time_launches(N, launch_store<2>, &c), (double)c.n_pix * 144);
   report("stores: 36 x dword nontemporal", time_launches(N, launch_store<3>, &c), (double)c.n_pix * 144);
   report("stores: 18 x dwordx2, 512 B runs", time_launches(N, launch_store<4>, &c), (double)c.n_pix * 144);
-  const char* names[] = {"lab v0: copy of product", "lab v1: no stores", "lab v2: no pyramid loads", "lab v3: persistent 256 blocks", "lab v4: persistent 512 blocks", "lab v5: 2 blocks/CU", "lab v6: 3 blocks/CU", "lab v7: 4 blocks/CU"};
-  for (int v = 0; v < 8; ++v) {
-    c.variant = v;
-    if (rc_lab_lookup(c.vol, &c.lay, c.coords, 2, c.out, v, 0) != 0) continue;
-    report(names[v], time_launches(N, launch_lab, &c), alg);
-  }
   return 0;
 }
