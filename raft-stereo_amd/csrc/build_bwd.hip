@@ -87,19 +87,21 @@ typedef short s4v __attribute__((ext_vector_type(4)));
 
 constexpr int GT = 512;  // threads: 8 waves x 32 feature rows
 constexpr int TS = 64;   // output columns per workgroup
+constexpr int TMF = 256; // feature rows (channels) per workgroup
 
 template <typename T> struct gemm_cfg {
   static constexpr bool IS16 = !std::is_same<T, float>::value;
   static constexpr int EPS = 16 / (int)sizeof(T);
-  static constexpr int KC = IS16 ? 256 : 64;      // contraction chunk held in LDS
-  static constexpr int KSTEP = IS16 ? 32 : 16;    // contraction elements per operand load
-  static constexpr int PN = KC + EPS;             // pitch of the [n][k] image (rows stay 16-byte aligned,
-                                                  // and 16 consecutive rows fall on different bank quads)
-  static constexpr int PT = TS + 16;              // pitch of the [k][n] image (as the build's staged tile)
-  static constexpr int LDS_ELEMS = (TS * PN > KC * PT) ? TS * PN : KC * PT;
+  static constexpr int KC = 128 / (int)sizeof(T);  // contraction chunk: a staged row is 128 bytes
+  static constexpr int KSTEP = IS16 ? 32 : 16;     // contraction elements per operand piece
+  static constexpr int PA = KC + EPS;              // pitch of the feature image [m][k] and of the plain slab
+                                                   // image [n][k]: 16 consecutive rows hit different bank quads
+  static constexpr int PT = TS + 16;               // pitch of the transposed slab image [k][n]
+  static constexpr int FEAT_ELEMS = TMF * PA;
+  static constexpr int SLAB_ELEMS = (TS * PA > KC * PT) ? TS * PA : KC * PT;
 };
 
-// 16 bytes (one operand piece of 8 / 4 consecutive k) of a feature row, zero past the end of the row
+// 16 bytes of a feature row starting at element k, zero past the end of the row
 template <typename T>
 __device__ __forceinline__ u4v load_feat(const T* __restrict__ row, int k, int K, bool vec) {
   constexpr int EPS = 16 / (int)sizeof(T);
@@ -110,48 +112,72 @@ __device__ __forceinline__ u4v load_feat(const T* __restrict__ row, int k, int K
   return *reinterpret_cast<u4v*>(tmp);
 }
 
-// 8 bytes (4 consecutive k of a 16-bit feature row), zero past the end of the row
-template <typename T>
-__device__ __forceinline__ uint2 load_feat4(const T* __restrict__ row, int k, int K, bool vec) {
-  typedef uint32_t u2v_a4 __attribute__((ext_vector_type(2), aligned(4)));
-  if (vec && k + 4 <= K) {
-    const u2v_a4 v = *reinterpret_cast<const u2v_a4*>(row + k);
-    return make_uint2(v[0], v[1]);
-  }
-  alignas(8) T tmp[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) tmp[e] = (k + e < K) ? row[k + e] : (T)0.0f;
-  return *reinterpret_cast<uint2*>(tmp);
-}
-
-// Out[b, m, h, n] = sum_k Feat[b, m, h, k] * G(k, n) for one image row (b,h) and 64 columns n per
-// workgroup; M feature channels, 32 per wave.
+// Out[b, m, h, n] = sum_k Feat[b, m, h, k] * G(k, n) for one image row (b,h), 64 columns n and 256
+// channels m per workgroup (32 per wave).
 //   TRANS = false (d fmap1):  n = w1, k = w2, G(k,n) = dC[bh][n][k]  -> LDS image [n][k], plain 16-byte reads
 //   TRANS = true  (d fmap2):  n = w2, k = w1, G(k,n) = dC[bh][k][n]  -> LDS image [k][n], transposing reads
-// dC rows are ldc (a multiple of 32) long and zero beyond W2.  The MFMA rows are n and its columns are
-// the feature channels, so a lane ends up with 4 consecutive n of one channel: one 8-byte store.
-// Feature rows go from global memory straight into MFMA operands (each element is used once per
-// workgroup); the 64 x K slab of dC is staged through LDS in chunks of KC.
+// dC rows are ldc (a multiple of 32) long and zero beyond W2.  Both operands are staged through
+// LDS in chunks of KC along k with coalesced 16-byte loads (the next chunk is in flight during the
+// MFMAs).  The MFMA rows are n and its columns are the channels, so a lane ends up with 4
+// consecutive n of one channel: one 8-byte store.
 template <typename T, bool TRANS>
 __global__ __launch_bounds__(GT) void gemm_rows_kernel(const T* __restrict__ feat, const T* __restrict__ dC,
                                                        T* __restrict__ out, int M, int N, int K, int H, int W1,
-                                                       int ldc, bool vec) {
+                                                       int ldc, bool vec, int n_slabs, int n_mgroups, int n_rows) {
   using C = gemm_cfg<T>;
-  __shared__ __attribute__((aligned(16))) T lds[C::LDS_ELEMS];
-  const int n0 = blockIdx.x * TS;
-  const int bh = blockIdx.z, b = bh / H, h = bh - b * H;
+  __shared__ __attribute__((aligned(16))) T featI[C::FEAT_ELEMS];
+  __shared__ __attribute__((aligned(16))) T slabI[C::SLAB_ELEMS];
+  // XCD-aware mapping: the column slabs (and channel groups) of one image row get block ids
+  // congruent mod 8 (one XCD, one L2), since they all re-read that row's features / dC
+  const int id = blockIdx.x;
+  const int j = id >> 3;
+  const int per_row = n_slabs * n_mgroups;
+  const int bh = (j / per_row) * 8 + (id & 7);
+  if (bh >= n_rows) return;
+  const int sub = j % per_row;
+  const int n0 = (sub % n_slabs) * TS;
+  const int mb = (sub / n_slabs) * TMF;
+  const int b = bh / H, h = bh - b * H;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, li = lane & 15;
-  const int m0 = blockIdx.y * 256 + wave * 32;
 
-  // this lane's two feature rows (clamped: rows past M are computed and dropped)
-  const T* frow[2];
-#pragma unroll
-  for (int x = 0; x < 2; ++x) {
-    const int m = min(m0 + 16 * x + li, M - 1);
-    frow[x] = feat + (((int64_t)b * M + m) * H + h) * K;
-  }
+  // staging roles: thread -> (row, 16-byte segment) of the 128-byte rows
+  const int srow = threadIdx.x >> 3, sseg = threadIdx.x & 7;
   const T* dCrow = dC + (int64_t)bh * W1 * ldc;
+
+  u4v rf[4], rs;
+  auto load_chunk = [&](int kc0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = mb + srow + 64 * j;
+      rf[j] = (u4v)(0u);
+      if (m < M) rf[j] = load_feat<T>(feat + (((int64_t)b * M + m) * H + h) * K, kc0 + sseg * C::EPS, K, vec);
+    }
+    rs = (u4v)(0u);
+    if constexpr (!TRANS) {
+      // image [n][k]: row n0 + srow of dC, columns kc0 .. kc0 + KC
+      const int n = n0 + srow, k = kc0 + sseg * C::EPS;
+      if (n < N && k < ldc) rs = *reinterpret_cast<const u4v*>(dCrow + (int64_t)n * ldc + k);
+    } else {
+      // image [k][n]: row kc0 + r of dC (a w1), columns n0 .. n0 + 64 (a 64-column row is TS / EPS segments)
+      constexpr int SEGS = TS / C::EPS;
+      const int r = threadIdx.x / SEGS, sg = threadIdx.x - r * SEGS;
+      const int k = kc0 + r, n = n0 + sg * C::EPS;
+      if (k < K && n < ldc) rs = *reinterpret_cast<const u4v*>(dCrow + (int64_t)k * ldc + n);
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<u4v*>(featI + (srow + 64 * j) * C::PA + sseg * C::EPS) = rf[j];
+    if constexpr (!TRANS) {
+      *reinterpret_cast<u4v*>(slabI + srow * C::PA + sseg * C::EPS) = rs;
+    } else {
+      constexpr int SEGS = TS / C::EPS;
+      const int r = threadIdx.x / SEGS, sg = threadIdx.x - r * SEGS;
+      *reinterpret_cast<u4v*>(slabI + r * C::PT + sg * C::EPS) = rs;
+    }
+  };
 
   f4v acc[4][2];
 #pragma unroll
@@ -160,86 +186,62 @@ __global__ __launch_bounds__(GT) void gemm_rows_kernel(const T* __restrict__ fea
     acc[y][1] = (f4v)(0.f);
   }
 
-  constexpr int NKS = C::KC / C::KSTEP;  // operand steps per chunk
+  load_chunk(0);
   for (int kc0 = 0; kc0 < K; kc0 += C::KC) {
-    // ---- this chunk's feature pieces: all loads issued up front, in flight while the slab is staged.
-    // 16-bit, plain image: lane (g, li) holds k = kk + 8 g .. + 7 of feature row li and of slab column
-    // li; transposed image: the transposing read hands group g the k = kk + 4 g + {0..3} and
-    // kk + 16 + 4 g + {0..3}, so the feature piece is gathered to match.  f32: 16 k per step as 4
-    // exact-f32 MFMAs, lane (g, li) supplies k = kk + 4 g + e in sub-step e.
-    u4v fa[NKS][2];
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-      const int k = kc0 + ks * C::KSTEP;
-#pragma unroll
-      for (int x = 0; x < 2; ++x) {
-        if (k >= K) {  // wave-uniform
-          fa[ks][x] = (u4v)(0u);
-        } else if constexpr (!C::IS16) {
-          fa[ks][x] = load_feat<T>(frow[x], k + 4 * g, K, vec);
-        } else if constexpr (!TRANS) {
-          fa[ks][x] = load_feat<T>(frow[x], k + 8 * g, K, vec);
-        } else {
-          const uint2 lo = load_feat4<T>(frow[x], k + 4 * g, K, vec);
-          const uint2 hi = load_feat4<T>(frow[x], k + 16 + 4 * g, K, vec);
-          fa[ks][x] = (u4v){lo.x, lo.y, hi.x, hi.y};
-        }
-      }
-    }
-
+    __syncthreads();  // previous chunk's readers are done
+    store_chunk();
     __syncthreads();
-    // ---- stage the slab chunk, zero filled outside dC
-    if constexpr (!TRANS) {
-      // image [n][k]: row n0 + r of dC, columns kc0 .. kc0 + KC
-      constexpr int SEGS = C::KC / C::EPS;
-      for (int e = threadIdx.x; e < TS * SEGS; e += GT) {
-        const int r = e / SEGS, sgm = e - r * SEGS;
-        const int n = n0 + r, k = kc0 + sgm * C::EPS;
-        u4v v = (u4v)(0u);
-        if (n < N && k < ldc) v = *reinterpret_cast<const u4v*>(dCrow + (int64_t)n * ldc + k);
-        *reinterpret_cast<u4v*>(lds + r * C::PN + sgm * C::EPS) = v;
-      }
-    } else {
-      // image [k][n]: row kc0 + r of dC (a w1), columns n0 .. n0 + 64
-      constexpr int SEGS = TS / C::EPS;
-      for (int e = threadIdx.x; e < C::KC * SEGS; e += GT) {
-        const int r = e / SEGS, sgm = e - r * SEGS;
-        const int k = kc0 + r, n = n0 + sgm * C::EPS;
-        u4v v = (u4v)(0u);
-        if (k < K && n < ldc) v = *reinterpret_cast<const u4v*>(dCrow + (int64_t)k * ldc + n);
-        *reinterpret_cast<u4v*>(lds + r * C::PT + sgm * C::EPS) = v;
-      }
-    }
-    __syncthreads();
+    if (kc0 + C::KC < K) load_chunk(kc0 + C::KC);
 
+    const T* frow0 = featI + (wave * 32 + li) * C::PA;  // this lane's channel rows: + 16 x rows
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
+    for (int ks = 0; ks < C::KC / C::KSTEP; ++ks) {
       const int kk = ks * C::KSTEP;  // offset inside the chunk
       if (kc0 + kk >= K) break;      // wave-uniform
       if constexpr (C::IS16) {
+        // plain image: lane (g, li) holds k = kk + 8 g .. + 7 of channel row li and of slab column li;
+        // transposed image: the transposing read hands group g the k = kk + 4 g + {0..3} and
+        // kk + 16 + 4 g + {0..3}, so the channel piece is gathered to match
+        s8v fa[2];
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+          const T* fr = frow0 + 16 * x * C::PA + kk;
+          if constexpr (!TRANS) {
+            fa[x] = *reinterpret_cast<const s8v*>(fr + 8 * g);
+          } else {
+            const s4v lo = *reinterpret_cast<const s4v*>(fr + 4 * g);
+            const s4v hi = *reinterpret_cast<const s4v*>(fr + 16 + 4 * g);
+            fa[x] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          }
+        }
 #pragma unroll
         for (int y = 0; y < 4; ++y) {
           s8v gb;
           if constexpr (!TRANS) {
-            gb = *reinterpret_cast<const s8v*>(lds + (16 * y + li) * C::PN + kk + 8 * g);
+            gb = *reinterpret_cast<const s8v*>(slabI + (16 * y + li) * C::PA + kk + 8 * g);
           } else {
             typedef s4v __attribute__((address_space(3))) * lds_s4p;
-            const short* base = reinterpret_cast<const short*>(lds);
+            const short* base = reinterpret_cast<const short*>(slabI);
             const int e = (kk + 4 * g + (li >> 2)) * C::PT + 16 * y + 4 * (li & 3);
             const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(base + e));
             const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(base + e + 16 * C::PT));
             gb = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
           }
 #pragma unroll
-          for (int x = 0; x < 2; ++x) acc[y][x] = mfma16<T>(gb, __builtin_bit_cast(s8v, fa[ks][x]), acc[y][x]);
+          for (int x = 0; x < 2; ++x) acc[y][x] = mfma16<T>(gb, fa[x], acc[y][x]);
         }
       } else {
-        const float* lf = reinterpret_cast<const float*>(lds);
+        // f32: 16 k per step as 4 exact-f32 MFMAs; lane (g, li) supplies k = kk + 4 g + e in sub-step e
+        const float* lf = reinterpret_cast<const float*>(slabI);
+        f4v fa[2];
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+          fa[x] = *reinterpret_cast<const f4v*>(reinterpret_cast<const float*>(frow0) + 16 * x * C::PA + kk + 4 * g);
 #pragma unroll
         for (int y = 0; y < 4; ++y) {
           f4v gb;
           if constexpr (!TRANS) {
-            gb = *reinterpret_cast<const f4v*>(lf + (16 * y + li) * C::PN + kk + 4 * g);
+            gb = *reinterpret_cast<const f4v*>(lf + (16 * y + li) * C::PA + kk + 4 * g);
           } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) gb[e] = lf[(kk + 4 * g + e) * C::PT + 16 * y + li];
@@ -248,18 +250,17 @@ __global__ __launch_bounds__(GT) void gemm_rows_kernel(const T* __restrict__ fea
           for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int x = 0; x < 2; ++x)
-              acc[y][x] = __builtin_amdgcn_mfma_f32_16x16x4f32(gb[e], __builtin_bit_cast(f4v, fa[ks][x])[e],
-                                                               acc[y][x], 0, 0, 0);
+              acc[y][x] = __builtin_amdgcn_mfma_f32_16x16x4f32(gb[e], fa[x][e], acc[y][x], 0, 0, 0);
         }
       }
     }
   }
 
-  // lane (g, li): columns n0 + 16 y + 4 g + {0..3} of channel m0 + 16 x + li
+  // lane (g, li): columns n0 + 16 y + 4 g + {0..3} of channel mb + 32 wave + 16 x + li
   const bool vec_out = (N % 4 == 0);
 #pragma unroll
   for (int x = 0; x < 2; ++x) {
-    const int m = m0 + 16 * x + li;
+    const int m = mb + wave * 32 + 16 * x + li;
     if (m >= M) continue;
     T* orow = out + (((int64_t)b * M + m) * H + h) * N;
 #pragma unroll
@@ -297,17 +298,20 @@ int run_bwd(const float* gvol, const rc_layout* lay, const void* f1, const void*
   int rc = rc_check_launch("rc_build_bwd(unskew)");
   if (rc) return rc;
 
-  const unsigned my = (unsigned)((D + 255) / 256);
+  const int my = (D + TMF - 1) / TMF;
+  const int64_t rows8 = (BH + 7) / 8 * 8;
   const bool v2 = (W2 * sizeof(T)) % 4 == 0 && (uintptr_t)f2 % 4 == 0;
   const bool v1 = (W1 * sizeof(T)) % 4 == 0 && (uintptr_t)f1 % 4 == 0;
   // d fmap1 = f2 . dC^T : n = w1, k = w2
-  hipLaunchKernelGGL((gemm_rows_kernel<T, false>), dim3((W1 + TS - 1) / TS, my, (unsigned)BH), dim3(GT), 0, st,
-                     (const T*)f2, (const T*)dC, (T*)df1, D, W1, W2, H, W1, W2p, v2);
+  const int ns1 = (W1 + TS - 1) / TS, ns2 = (W2 + TS - 1) / TS;
+  RC_REQUIRE(rows8 * (ns1 > ns2 ? ns1 : ns2) * my < (1ll << 31), RC_EINVAL, "grid too large");
+  hipLaunchKernelGGL((gemm_rows_kernel<T, false>), dim3((unsigned)(rows8 * ns1 * my), 1, 1), dim3(GT), 0, st,
+                     (const T*)f2, (const T*)dC, (T*)df1, D, W1, W2, H, W1, W2p, v2, ns1, my, (int)BH);
   rc = rc_check_launch("rc_build_bwd(df1)");
   if (rc) return rc;
   // d fmap2 = f1 . dC : n = w2, k = w1
-  hipLaunchKernelGGL((gemm_rows_kernel<T, true>), dim3((W2 + TS - 1) / TS, my, (unsigned)BH), dim3(GT), 0, st,
-                     (const T*)f1, (const T*)dC, (T*)df2, D, W2, W1, H, W1, W2p, v1);
+  hipLaunchKernelGGL((gemm_rows_kernel<T, true>), dim3((unsigned)(rows8 * ns2 * my), 1, 1), dim3(GT), 0, st,
+                     (const T*)f1, (const T*)dC, (T*)df2, D, W2, W1, H, W1, W2p, v1, ns2, my, (int)BH);
   return rc_check_launch("rc_build_bwd(df2)");
 }
 
