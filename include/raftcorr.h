@@ -41,6 +41,7 @@ extern "C" {
 #define RC_VERSION 100          /* 0.1.0 */
 #define RC_MAX_LEVELS 4
 #define RC_MAX_RADIUS 8
+#define RC_MAX_FUSED_LOOKUPS 32  /* lookups one rc_lookup_bwd_dense call can take */
 
 /* element types of feature maps / volumes */
 enum { RC_F32 = 0, RC_F16 = 1, RC_BF16 = 2 };
@@ -137,6 +138,25 @@ int rc_lookup_bwd(const float* coords, int coords_channels, const float* grad_ou
 int64_t rc_build_bwd_work_bytes(const rc_layout* glay, int in_dtype);
 int rc_build_bwd(const float* grad_vol, const rc_layout* glay, const void* f1, const void* f2,
                  void* df1, void* df2, int64_t D, int in_dtype, void* work, void* stream);
+
+/*
+ * The same adjoint for a whole forward pass at once.  rc_lookup_bwd_dense takes the coords and
+ * grad_out of up to RC_MAX_FUSED_LOOKUPS lookups (HOST arrays of device pointers, shapes as in
+ * rc_lookup_fwd) and writes the dense gradient of level 0, pooled levels folded in and scaled by
+ * 1/sqrt(D): dense_grad[b*H + h][w1][w2] of `out_dtype`, rows rc_dense_grad_ld(glay) elements
+ * long (zero beyond W2), B*H*W1*ld elements in all.  It replaces one rc_lookup_bwd per lookup
+ * (autograd of corr.py:127-146 / sampler_kernel.cu:63-105 called once per GRU iteration) plus the
+ * pyramid fold of rc_build_bwd, without ever touching a gradient pyramid.  rc_build_bwd_dense
+ * then contracts it with the feature maps (autograd of corr.py:154-156); df1/df2 and dense_grad
+ * have the feature dtype.  Sums over lookups are formed with LDS float atomics: the order, and
+ * so the last bit, can differ between runs.
+ */
+int64_t rc_dense_grad_ld(const rc_layout* glay);
+int rc_lookup_bwd_dense(const float* const* coords_list, const float* const* grad_out_list,
+                        int n_lookups, int coords_channels, void* dense_grad, const rc_layout* glay,
+                        int64_t D, int out_dtype, int radius, int coord_mode, void* stream);
+int rc_build_bwd_dense(const void* dense_grad, const rc_layout* glay, const void* f1, const void* f2,
+                       void* df1, void* df2, int64_t D, int in_dtype, void* stream);
 
 /*
  * Drop-in for the reference's `corr_sampler` extension (sampler/sampler.cpp:48-51): one

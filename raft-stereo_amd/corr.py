@@ -83,7 +83,7 @@ def _check_coords(coords, B, H, W1, device):
 class _BuildFn(torch.autograd.Function):
     """Builds the pyramid into block.volume and returns a 1-element token that ties every
     lookup to the build in the autograd graph.  Its backward runs once, after all lookups'
-    backwards have accumulated into block.grad_volume."""
+    backwards have queued their (coords, grad_out) in block._pending."""
 
     @staticmethod
     def forward(ctx, fmap1, fmap2, block):
@@ -96,20 +96,40 @@ class _BuildFn(torch.autograd.Function):
     def backward(ctx, _grad_token):
         fmap1, fmap2 = ctx.saved_tensors
         block = ctx.block
-        gvol = block.grad_volume
-        block.grad_volume = None
-        if gvol is None:          # no lookup took part in the loss
+        pending, block._pending = block._pending, []
+        if not pending:           # no lookup took part in the loss
             return torch.zeros_like(fmap1), torch.zeros_like(fmap2), None
         df1, df2 = torch.empty_like(fmap1), torch.empty_like(fmap2)
         lay = block.grad_layout
-        with torch.cuda.device(fmap1.device):
-            nbytes = lib.rc_build_bwd_work_bytes(lay, block.in_dtype)
-            if nbytes < 0:
-                raise _lib.RaftCorrError("rc_build_bwd_work_bytes rejected the layout")
-            work = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=fmap1.device)
-            check(lib.rc_build_bwd(gvol.data_ptr(), lay, fmap1.data_ptr(), fmap2.data_ptr(), df1.data_ptr(),
-                                   df2.data_ptr(), block.D, block.in_dtype, work.data_ptr(),
-                                   _stream(fmap1.device)), "rc_build_bwd")
+        dev = fmap1.device
+        with torch.cuda.device(dev):
+            st = _stream(dev)
+            if len(pending) <= _lib.RC_MAX_FUSED_LOOKUPS:
+                # one fused adjoint of all lookups -> dense gradient of level 0 -> two contractions
+                ld = int(lib.rc_dense_grad_ld(lay))
+                dense = torch.empty(block.B * block.H * block.W1 * ld, dtype=fmap1.dtype, device=dev)
+                n = len(pending)
+                cl = (ctypes.c_void_p * n)(*[c.data_ptr() for c, _ in pending])
+                gl = (ctypes.c_void_p * n)(*[g.data_ptr() for _, g in pending])
+                check(lib.rc_lookup_bwd_dense(cl, gl, n, pending[0][0].shape[1], dense.data_ptr(), lay, block.D,
+                                              block.in_dtype, block.radius, block.coord_mode, st),
+                      "rc_lookup_bwd_dense")
+                check(lib.rc_build_bwd_dense(dense.data_ptr(), lay, fmap1.data_ptr(), fmap2.data_ptr(),
+                                             df1.data_ptr(), df2.data_ptr(), block.D, block.in_dtype, st),
+                      "rc_build_bwd_dense")
+            else:
+                # more lookups than one fused call takes: accumulate into a float gradient pyramid
+                gvol = torch.zeros(lay.total, dtype=torch.float32, device=dev)
+                for coords, grad_out in pending:
+                    check(lib.rc_lookup_bwd(coords.data_ptr(), coords.shape[1], grad_out.data_ptr(), gvol.data_ptr(),
+                                            lay, block.radius, block.coord_mode, st), "rc_lookup_bwd")
+                nbytes = lib.rc_build_bwd_work_bytes(lay, block.in_dtype)
+                if nbytes < 0:
+                    raise _lib.RaftCorrError("rc_build_bwd_work_bytes rejected the layout")
+                work = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=dev)
+                check(lib.rc_build_bwd(gvol.data_ptr(), lay, fmap1.data_ptr(), fmap2.data_ptr(), df1.data_ptr(),
+                                       df2.data_ptr(), block.D, block.in_dtype, work.data_ptr(), st),
+                      "rc_build_bwd")
         return df1, df2, None
 
 
@@ -122,17 +142,11 @@ class _LookupFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
+        # nothing is computed here: the build's backward, which autograd runs after every lookup's,
+        # takes all (coords, grad_out) pairs in one fused call
         (coords,) = ctx.saved_tensors
-        block = ctx.block
-        grad_out = grad_out.float().contiguous()        # core/corr.py:27
-        dev = coords.device
-        with torch.cuda.device(dev):
-            if block.grad_volume is None:
-                block.grad_volume = torch.zeros(block.grad_layout.total, dtype=torch.float32, device=dev)
-            check(lib.rc_lookup_bwd(coords.data_ptr(), coords.shape[1], grad_out.data_ptr(),
-                                    block.grad_volume.data_ptr(), block.grad_layout, block.radius,
-                                    block.coord_mode, _stream(dev)), "rc_lookup_bwd")
-        return torch.zeros(1, dtype=torch.float32, device=dev), None, None
+        ctx.block._pending.append((coords, grad_out.float().contiguous()))        # core/corr.py:27
+        return torch.zeros(1, dtype=torch.float32, device=coords.device), None, None
 
 
 class CorrBlock1DHip:
@@ -164,7 +178,7 @@ class CorrBlock1DHip:
         check(lib.rc_pyramid_layout(B, H, W1, W2, num_levels, self.vol_dtype, self.layout), "rc_pyramid_layout")
         check(lib.rc_pyramid_layout(B, H, W1, W2, num_levels, _lib.RC_F32, self.grad_layout), "rc_pyramid_layout")
         self.volume = None
-        self.grad_volume = None
+        self._pending = []              # (coords, grad_out) of lookups whose backward has run
         fmap1, fmap2 = fmap1.contiguous(), fmap2.contiguous()
         if torch.is_grad_enabled() and (fmap1.requires_grad or fmap2.requires_grad):
             self._token = _BuildFn.apply(fmap1, fmap2, self)

@@ -282,37 +282,46 @@ __global__ __launch_bounds__(GT) void gemm_rows_kernel(const T* __restrict__ fea
   }
 }
 
+// the two contractions from a dense dC [BH][W1][W2p]
+template <typename T>
+int run_gemms(const void* dCv, const rc_layout* lay, const void* f1, const void* f2, void* df1, void* df2, int D,
+              hipStream_t st) {
+  const int W1 = (int)lay->W1, W2 = (int)lay->W2, H = (int)lay->H;
+  const int W2p = (int)round_up(W2, 32);
+  const int64_t BH = lay->B * lay->H;
+  const T* dC = reinterpret_cast<const T*>(dCv);
+  const int my = (D + TMF - 1) / TMF;
+  const int64_t rows8 = (BH + 7) / 8 * 8;
+  const bool v2 = (W2 * sizeof(T)) % 4 == 0 && (uintptr_t)f2 % 4 == 0;
+  const bool v1 = (W1 * sizeof(T)) % 4 == 0 && (uintptr_t)f1 % 4 == 0;
+  const int ns1 = (W1 + TS - 1) / TS, ns2 = (W2 + TS - 1) / TS;
+  RC_REQUIRE(rows8 * (ns1 > ns2 ? ns1 : ns2) * my < (1ll << 31), RC_EINVAL, "grid too large");
+  // d fmap1 = f2 . dC^T : n = w1, k = w2
+  hipLaunchKernelGGL((gemm_rows_kernel<T, false>), dim3((unsigned)(rows8 * ns1 * my), 1, 1), dim3(GT), 0, st,
+                     (const T*)f2, dC, (T*)df1, D, W1, W2, H, W1, W2p, v2, ns1, my, (int)BH);
+  int rc = rc_check_launch("rc_build_bwd(df1)");
+  if (rc) return rc;
+  // d fmap2 = f1 . dC : n = w2, k = w1
+  hipLaunchKernelGGL((gemm_rows_kernel<T, true>), dim3((unsigned)(rows8 * ns2 * my), 1, 1), dim3(GT), 0, st,
+                     (const T*)f1, dC, (T*)df2, D, W2, W1, H, W1, W2p, v1, ns2, my, (int)BH);
+  return rc_check_launch("rc_build_bwd(df2)");
+}
+
 template <typename T>
 int run_bwd(const float* gvol, const rc_layout* lay, const void* f1, const void* f2, void* df1, void* df2,
             int D, void* work, hipStream_t st) {
   const rc_dev_layout d = rc_to_dev(lay);
-  const int W1 = d.W1, W2 = d.W2, H = d.H;
+  const int W1 = d.W1, W2 = d.W2;
   const int W2p = (int)round_up(W2, 32);
   const int64_t BH = lay->B * lay->H;
   T* dC = reinterpret_cast<T*>(work);
   const float scale = (float)(1.0 / sqrt((double)D));
   RC_REQUIRE(BH < 65536, RC_EINVAL, "B*H=%lld exceeds the grid z range; split the batch", (long long)BH);
-
   hipLaunchKernelGGL((unskew_fold_kernel<T>), dim3((W1 + UT - 1) / UT, (W2p + UT - 1) / UT, (unsigned)BH),
                      dim3(256), 0, st, gvol, d, dC, W2p, scale);
   int rc = rc_check_launch("rc_build_bwd(unskew)");
   if (rc) return rc;
-
-  const int my = (D + TMF - 1) / TMF;
-  const int64_t rows8 = (BH + 7) / 8 * 8;
-  const bool v2 = (W2 * sizeof(T)) % 4 == 0 && (uintptr_t)f2 % 4 == 0;
-  const bool v1 = (W1 * sizeof(T)) % 4 == 0 && (uintptr_t)f1 % 4 == 0;
-  // d fmap1 = f2 . dC^T : n = w1, k = w2
-  const int ns1 = (W1 + TS - 1) / TS, ns2 = (W2 + TS - 1) / TS;
-  RC_REQUIRE(rows8 * (ns1 > ns2 ? ns1 : ns2) * my < (1ll << 31), RC_EINVAL, "grid too large");
-  hipLaunchKernelGGL((gemm_rows_kernel<T, false>), dim3((unsigned)(rows8 * ns1 * my), 1, 1), dim3(GT), 0, st,
-                     (const T*)f2, (const T*)dC, (T*)df1, D, W1, W2, H, W1, W2p, v2, ns1, my, (int)BH);
-  rc = rc_check_launch("rc_build_bwd(df1)");
-  if (rc) return rc;
-  // d fmap2 = f1 . dC : n = w2, k = w1
-  hipLaunchKernelGGL((gemm_rows_kernel<T, true>), dim3((unsigned)(rows8 * ns2 * my), 1, 1), dim3(GT), 0, st,
-                     (const T*)f1, (const T*)dC, (T*)df2, D, W2, W1, H, W1, W2p, v1, ns2, my, (int)BH);
-  return rc_check_launch("rc_build_bwd(df2)");
+  return run_gemms<T>(dC, lay, f1, f2, df1, df2, D, st);
 }
 
 int64_t elem_size(int dtype) { return dtype == RC_F32 ? 4 : 2; }
@@ -340,6 +349,23 @@ extern "C" int rc_build_bwd(const float* grad_vol, const rc_layout* lay, const v
     case RC_F32: return run_bwd<float>(grad_vol, lay, f1, f2, df1, df2, (int)D, work, st);
     case RC_F16: return run_bwd<rc_half>(grad_vol, lay, f1, f2, df1, df2, (int)D, work, st);
     case RC_BF16: return run_bwd<rc_bf16>(grad_vol, lay, f1, f2, df1, df2, (int)D, work, st);
+  }
+  rc_set_error("unknown in_dtype %d", in_dtype);
+  return RC_EUNSUPPORTED;
+}
+
+extern "C" int rc_build_bwd_dense(const void* dense_grad, const rc_layout* lay, const void* f1, const void* f2,
+                                  void* df1, void* df2, int64_t D, int in_dtype, void* stream) {
+  RC_REQUIRE(dense_grad && lay && f1 && f2 && df1 && df2, RC_EINVAL, "null pointer argument");
+  int rc = rc_validate_layout(lay);
+  if (rc) return rc;
+  RC_REQUIRE(D >= 1 && D < (1 << 20), RC_EINVAL, "bad feature depth D=%lld", (long long)D);
+  RC_REQUIRE((uintptr_t)dense_grad % 16 == 0, RC_EINVAL, "dense gradient must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  switch (in_dtype) {
+    case RC_F32: return run_gemms<float>(dense_grad, lay, f1, f2, df1, df2, (int)D, st);
+    case RC_F16: return run_gemms<rc_half>(dense_grad, lay, f1, f2, df1, df2, (int)D, st);
+    case RC_BF16: return run_gemms<rc_bf16>(dense_grad, lay, f1, f2, df1, df2, (int)D, st);
   }
   rc_set_error("unknown in_dtype %d", in_dtype);
   return RC_EUNSUPPORTED;

@@ -13,6 +13,8 @@
 // channel plane, 256 B per wave store.
 #include "rc_common.h"
 
+#include <math.h>
+
 namespace {
 
 constexpr int LK_THREADS = 256;  // 4 waves, each its own 64-pixel chunk
@@ -359,6 +361,211 @@ __global__ __launch_bounds__(LK_THREADS) void lookup_bwd_kernel(const float* __r
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused adjoint of up to RC_MAX_FUSED_LOOKUPS lookups, written as the DENSE gradient of level 0:
+//   dC[bh][w1][w2] = 1/sqrt(D) * sum over lookups, levels i, taps of  2^-i * (tap gradient landing on w2 >> i)
+// in the feature type, rows `ldc` long (zero beyond W2).  This is what rc_lookup_bwd (once per
+// lookup, into the f32 gradient pyramid) followed by the unskew/fold step of rc_build_bwd
+// produces, without the pyramid: a workgroup owns TP pixels of one image row, accumulates all
+// lookups into per-level rows in LDS (f32, ds_add_f32), folds the levels and writes each dense
+// row once.  The 256 threads are 256/TP groups of TP pixels; group q takes lookups q, q + 256/TP, ...
+struct adj_lists {
+  const float* coords[RC_MAX_FUSED_LOOKUPS];
+  const float* gout[RC_MAX_FUSED_LOOKUPS];
+};
+
+struct adj_dims {
+  int B, H, W1, W2, L, ldc, n, cc;
+  int width[RC_MAX_LEVELS];
+  int pitch[RC_MAX_LEVELS];  // LDS row pitch of level i (floats)
+  int base[RC_MAX_LEVELS];   // LDS offset of level i = TP * sum of the lower pitches
+};
+
+template <typename T, int R, int MODE, int TP>
+__global__ __launch_bounds__(256) void adjoint_dense_kernel(adj_lists lists, adj_dims d, T* __restrict__ dC,
+                                                            float scale) {
+  using WI = win_info<4, R, MODE>;
+  constexpr int NT = WI::NT, EXT = WI::EXT, NW = WI::NW;
+  constexpr int NG = 256 / TP;
+  extern __shared__ __attribute__((aligned(16))) float acc[];
+  __shared__ const float* s_coords[RC_MAX_FUSED_LOOKUPS];
+  __shared__ const float* s_gout[RC_MAX_FUSED_LOOKUPS];
+
+  const int tiles = (d.W1 + TP - 1) / TP;
+  const int bh = blockIdx.x / tiles;
+  const int c0 = (blockIdx.x - bh * tiles) * TP;
+  const int b = bh / d.H, h = bh - b * d.H;
+  const int p = threadIdx.x % TP, q = threadIdx.x / TP;
+  const int w1 = c0 + p;
+  const int64_t HW = (int64_t)d.H * d.W1;
+  const int total = d.base[d.L - 1] + TP * d.pitch[d.L - 1];  // floats of LDS in use
+
+  if (threadIdx.x < RC_MAX_FUSED_LOOKUPS) {
+    s_coords[threadIdx.x] = lists.coords[threadIdx.x];
+    s_gout[threadIdx.x] = lists.gout[threadIdx.x];
+  }
+  for (int e = threadIdx.x; e < total; e += 256) acc[e] = 0.f;
+  __syncthreads();
+
+  if (w1 < d.W1) {
+    for (int t = q; t < d.n; t += NG) {
+      const float x = s_coords[t][((int64_t)b * d.cc) * HW + (int64_t)h * d.W1 + w1];
+      const float* gp = s_gout[t] + ((int64_t)b * d.L * NT) * HW + (int64_t)h * d.W1 + w1;
+      for (int i = 0; i < d.L; ++i) {
+        const int Wi = d.width[i];
+        float g[NT];
+#pragma unroll
+        for (int k = 0; k < NT; ++k) g[k] = gp[((int64_t)i * NT + k) * HW];
+        const float xi = x * (1.0f / (float)(1 << i));
+        const float xf = floorf(xi);
+        const float a = xi - xf;
+        const int wbase = rc_safe_int(xf) - R - EXT;
+        if (wbase + NW - 1 < 0 || wbase >= Wi) continue;  // window outside the image
+
+        // tw[m] = gradient of window entry m (w2 of level i = wbase + m)
+        float tw[NW + 1];
+#pragma unroll
+        for (int m = 0; m <= NW; ++m) tw[m] = 0.f;
+        if constexpr (MODE == RC_COORD_EXACT) {
+          const float bw = 1.0f - a;
+#pragma unroll
+          for (int k = 0; k < NT; ++k) {
+            tw[k] += g[k] * bw;
+            tw[k + 1] += g[k] * a;
+          }
+        } else {
+          const float wm1 = (float)(Wi - 1);
+#pragma unroll
+          for (int k = 0; k < NT; ++k) {
+            int i0k;
+            float w0, w1w;
+            rc_gridsample_coords(xi, k - R, wm1, &i0k, &w0, &w1w);
+            const int dlt = i0k - (wbase + EXT + k);  // -1, 0 or +1 (the fp32 round trip can cross an integer)
+            const float a0 = g[k] * w0, a1 = g[k] * w1w;
+            tw[k] += dlt < 0 ? a0 : 0.f;
+            tw[k + 1] += dlt < 0 ? a1 : (dlt == 0 ? a0 : 0.f);
+            tw[k + 2] += dlt == 0 ? a1 : (dlt > 0 ? a0 : 0.f);
+            tw[k + 3] += dlt > 0 ? a1 : 0.f;
+          }
+        }
+        float* row = acc + d.base[i] + p * d.pitch[i];
+#pragma unroll
+        for (int m = 0; m < NW; ++m) {
+          const int w2 = wbase + m;
+          const bool ok = (unsigned)w2 < (unsigned)Wi;
+          atomicAdd(row + (ok ? w2 : 0), ok ? tw[m] : 0.f);  // branch-free: out-of-image entries add 0 to cell 0
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // fold the levels (a pooled cell spreads 2^-i of its gradient over its 2^i children) and write the
+  // dense rows, 8 consecutive w2 per thread
+  const int segs = d.ldc >> 3;
+  for (int e = threadIdx.x; e < TP * segs; e += 256) {
+    const int pp = e / segs, w20 = (e - pp * segs) * 8;
+    if (c0 + pp >= d.W1) continue;
+    float v[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int w2 = w20 + r;
+      float sum = 0.f, wgt = scale;
+      for (int i = 0; i < d.L; ++i) {
+        const int wi = w2 >> i;
+        if (wi < d.width[i]) sum += wgt * acc[d.base[i] + pp * d.pitch[i] + wi];
+        wgt *= 0.5f;
+      }
+      v[r] = w2 < d.W2 ? sum : 0.f;
+    }
+    T* dst = dC + ((int64_t)bh * d.W1 + c0 + pp) * d.ldc + w20;
+    if constexpr (sizeof(T) == 4) {
+      typedef float f4v __attribute__((ext_vector_type(4)));
+      reinterpret_cast<f4v*>(dst)[0] = (f4v){v[0], v[1], v[2], v[3]};
+      reinterpret_cast<f4v*>(dst)[1] = (f4v){v[4], v[5], v[6], v[7]};
+    } else {
+      typedef float f8v __attribute__((ext_vector_type(8)));
+      typedef T t8v __attribute__((ext_vector_type(8)));
+      const f8v f = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+      *reinterpret_cast<t8v*>(dst) = __builtin_convertvector(f, t8v);
+    }
+  }
+}
+
+template <typename T, int R, int MODE>
+int launch_adjoint_dense(const adj_lists& lists, adj_dims d, void* dC, float scale, hipStream_t st) {
+  // the largest pixel tile whose per-level rows fit in 64 KiB of LDS
+  int sum_pitch = 0;
+  for (int i = 0; i < d.L; ++i) {
+    d.pitch[i] = (d.width[i] + 31) / 32 * 32;
+    sum_pitch += d.pitch[i];
+  }
+  int tp = 64;
+  while (tp > 8 && (int64_t)tp * sum_pitch * 4 > 64 * 1024) tp >>= 1;
+  const int64_t lds = (int64_t)tp * sum_pitch * 4;
+  RC_REQUIRE(lds <= 160 * 1024 - 1024, RC_EUNSUPPORTED, "W2=%d is too wide for the fused adjoint", d.W2);
+  int off = 0;
+  for (int i = 0; i < d.L; ++i) {
+    d.base[i] = off;
+    off += tp * d.pitch[i];
+  }
+  const int64_t blocks = (int64_t)d.B * d.H * ((d.W1 + tp - 1) / tp);
+  RC_REQUIRE(blocks < (1ll << 31), RC_EINVAL, "too many pixels");
+#define RC_ADJ(TPV)                                                                                       \
+  case TPV: {                                                                                             \
+    static bool attr_set[64] = {};                                                                        \
+    int dev = 0;                                                                                          \
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {                                       \
+      rc_set_error("no current HIP device");                                                              \
+      return RC_ENODEVICE;                                                                                \
+    }                                                                                                     \
+    if (!attr_set[dev]) {                                                                                 \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&adjoint_dense_kernel<T, R, MODE, TPV>), \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);         \
+      if (e != hipSuccess) {                                                                              \
+        rc_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));                                    \
+        return (int)e;                                                                                    \
+      }                                                                                                   \
+      attr_set[dev] = true;                                                                               \
+    }                                                                                                     \
+    hipLaunchKernelGGL((adjoint_dense_kernel<T, R, MODE, TPV>), dim3((unsigned)blocks), dim3(256), (size_t)lds, \
+                       st, lists, d, (T*)dC, scale);                                                      \
+    break;                                                                                                \
+  }
+  switch (tp) {
+    RC_ADJ(64)
+    RC_ADJ(32)
+    RC_ADJ(16)
+    RC_ADJ(8)
+  }
+#undef RC_ADJ
+  return rc_check_launch("rc_lookup_bwd_dense");
+}
+
+template <typename T, int R>
+int launch_adjoint_dense_mode(const adj_lists& lists, const adj_dims& d, void* dC, float scale, int mode,
+                              hipStream_t st) {
+  return mode == RC_COORD_EXACT ? launch_adjoint_dense<T, R, RC_COORD_EXACT>(lists, d, dC, scale, st)
+                                : launch_adjoint_dense<T, R, RC_COORD_GRIDSAMPLE>(lists, d, dC, scale, st);
+}
+
+template <typename T>
+int dispatch_adjoint_dense(const adj_lists& lists, const adj_dims& d, void* dC, float scale, int radius, int mode,
+                           hipStream_t st) {
+  switch (radius) {
+    case 1: return launch_adjoint_dense_mode<T, 1>(lists, d, dC, scale, mode, st);
+    case 2: return launch_adjoint_dense_mode<T, 2>(lists, d, dC, scale, mode, st);
+    case 3: return launch_adjoint_dense_mode<T, 3>(lists, d, dC, scale, mode, st);
+    case 4: return launch_adjoint_dense_mode<T, 4>(lists, d, dC, scale, mode, st);
+    case 5: return launch_adjoint_dense_mode<T, 5>(lists, d, dC, scale, mode, st);
+    case 6: return launch_adjoint_dense_mode<T, 6>(lists, d, dC, scale, mode, st);
+    case 7: return launch_adjoint_dense_mode<T, 7>(lists, d, dC, scale, mode, st);
+    case 8: return launch_adjoint_dense_mode<T, 8>(lists, d, dC, scale, mode, st);
+  }
+  rc_set_error("radius %d outside 1..%d", radius, RC_MAX_RADIUS);
+  return RC_EUNSUPPORTED;
+}
+
 // bias[i]: the smallest multiple of the level's block-row count that keeps
 // g0 - (w1 >> i) / RB + nb - RC_WRAP_ROWS / RB non-negative for every window that overlaps the image
 void set_row_bias(rc_dev_layout& d, int rb, int nw) {
@@ -484,5 +691,43 @@ extern "C" int rc_lookup_bwd(const float* coords, int coords_channels, const flo
     case 7: return launch_bwd<7>(coords, coords_channels, grad_out, grad_vol, d, coord_mode, st);
     case 8: return launch_bwd<8>(coords, coords_channels, grad_out, grad_vol, d, coord_mode, st);
   }
+  return RC_EUNSUPPORTED;
+}
+
+extern "C" int64_t rc_dense_grad_ld(const rc_layout* glay) {
+  if (!glay || rc_validate_layout(glay)) return -1;
+  return (glay->W2 + 31) / 32 * 32;
+}
+
+extern "C" int rc_lookup_bwd_dense(const float* const* coords_list, const float* const* grad_out_list,
+                                   int n_lookups, int coords_channels, void* dense_grad, const rc_layout* glay,
+                                   int64_t D, int out_dtype, int radius, int coord_mode, void* stream) {
+  RC_REQUIRE(coords_list && grad_out_list && dense_grad && glay, RC_EINVAL, "null pointer argument");
+  RC_REQUIRE(n_lookups >= 1 && n_lookups <= RC_MAX_FUSED_LOOKUPS, RC_EUNSUPPORTED,
+             "n_lookups %d outside 1..%d", n_lookups, RC_MAX_FUSED_LOOKUPS);
+  int rc = check_common(glay, dense_grad, coords_list[0], grad_out_list[0], coords_channels, radius, coord_mode);
+  if (rc) return rc;
+  RC_REQUIRE(D >= 1 && D < (1 << 20), RC_EINVAL, "bad feature depth D=%lld", (long long)D);
+  adj_lists lists;
+  for (int t = 0; t < RC_MAX_FUSED_LOOKUPS; ++t) {
+    const int s = t < n_lookups ? t : 0;
+    RC_REQUIRE(coords_list[s] && grad_out_list[s], RC_EINVAL, "null pointer in the lookup lists");
+    lists.coords[t] = coords_list[s];
+    lists.gout[t] = grad_out_list[s];
+  }
+  adj_dims d;
+  d.B = (int)glay->B; d.H = (int)glay->H; d.W1 = (int)glay->W1; d.W2 = (int)glay->W2; d.L = glay->L;
+  d.ldc = (int)((glay->W2 + 31) / 32 * 32);
+  d.n = n_lookups;
+  d.cc = coords_channels;
+  for (int i = 0; i < RC_MAX_LEVELS; ++i) { d.width[i] = glay->width[i]; d.pitch[i] = 0; d.base[i] = 0; }
+  const float scale = (float)(1.0 / sqrt((double)D));
+  hipStream_t st = (hipStream_t)stream;
+  switch (out_dtype) {
+    case RC_F32: return dispatch_adjoint_dense<float>(lists, d, dense_grad, scale, radius, coord_mode, st);
+    case RC_F16: return dispatch_adjoint_dense<rc_half>(lists, d, dense_grad, scale, radius, coord_mode, st);
+    case RC_BF16: return dispatch_adjoint_dense<rc_bf16>(lists, d, dense_grad, scale, radius, coord_mode, st);
+  }
+  rc_set_error("unknown out_dtype %d", out_dtype);
   return RC_EUNSUPPORTED;
 }

@@ -237,6 +237,72 @@ def test_full_size_properties(R, dtype, shape):
         assert abs(lhs - rhs) <= 2e-2 * max(abs(lhs), abs(rhs), 1.0)
 
 
+# ------------------------------------------------------------------ fused adjoint vs the pyramid adjoint
+@pytest.mark.parametrize("dtype,mode", [(torch.float32, "gridsample"), (torch.float32, "exact"),
+                                        (torch.float16, "exact"), (torch.bfloat16, "exact")])
+@pytest.mark.parametrize("shape", [(2, 64, 3, 40, 45, 4, 4), (1, 256, 2, 180, 180, 4, 4), (1, 32, 2, 33, 20, 2, 3),
+                                   (1, 64, 1, 312, 312, 4, 4), (1, 32, 1, 760, 752, 4, 4)])
+def test_fused_adjoint_equals_pyramid_adjoint(R, dtype, mode, shape):
+    """rc_lookup_bwd_dense + rc_build_bwd_dense against rc_lookup_bwd (per lookup) + rc_build_bwd, both
+    through the C-ABI, on coordinates that include out-of-range and edge values."""
+    import ctypes
+    from raft_stereo_amd._lib import lib, check
+    from raft_stereo_amd.corr import COORD_MODES, _DT
+    B, D, H, W1, W2, L, r = shape
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    f1 = torch.randn((B, D, H, W1), generator=gen, device="cuda").to(dtype)
+    f2 = torch.randn((B, D, H, W2), generator=gen, device="cuda").to(dtype)
+    blk = R.CorrBlock1DHip(f1, f2, num_levels=L, radius=r, coord_mode=mode)
+    n = 5
+    st = torch.cuda.current_stream().cuda_stream
+    coords, gouts = [], []
+    for t in range(n):
+        x = torch.rand((B, 1, H, W1), generator=gen, device="cuda") * (W2 + 24) - 12
+        if t == 0:
+            x = torch.round(x)                          # integer-exact positions
+        coords.append(torch.cat([x, torch.zeros_like(x)], 1).contiguous())
+        gouts.append(torch.randn((B, L * (2 * r + 1), H, W1), generator=gen, device="cuda"))
+    lay = blk.grad_layout
+    # pyramid path
+    gvol = torch.zeros(lay.total, dtype=torch.float32, device="cuda")
+    for c, g in zip(coords, gouts):
+        check(lib.rc_lookup_bwd(c.data_ptr(), 2, g.data_ptr(), gvol.data_ptr(), lay, r, COORD_MODES[mode], st), "bwd")
+    work = torch.empty(int(lib.rc_build_bwd_work_bytes(lay, _DT[dtype])), dtype=torch.uint8, device="cuda")
+    a1, a2 = torch.empty_like(f1), torch.empty_like(f2)
+    check(lib.rc_build_bwd(gvol.data_ptr(), lay, f1.data_ptr(), f2.data_ptr(), a1.data_ptr(), a2.data_ptr(), D,
+                           _DT[dtype], work.data_ptr(), st), "build_bwd")
+    # fused path
+    ld = int(lib.rc_dense_grad_ld(lay))
+    dense = torch.full((B * H * W1 * ld,), float("nan"), dtype=dtype, device="cuda")
+    cl = (ctypes.c_void_p * n)(*[c.data_ptr() for c in coords])
+    gl = (ctypes.c_void_p * n)(*[g.data_ptr() for g in gouts])
+    check(lib.rc_lookup_bwd_dense(cl, gl, n, 2, dense.data_ptr(), lay, D, _DT[dtype], r, COORD_MODES[mode], st), "dense")
+    b1, b2 = torch.empty_like(f1), torch.empty_like(f2)
+    check(lib.rc_build_bwd_dense(dense.data_ptr(), lay, f1.data_ptr(), f2.data_ptr(), b1.data_ptr(), b2.data_ptr(), D,
+                                 _DT[dtype], st), "build_bwd_dense")
+    # the dense gradient equals what the unskew step left in `work` up to summation order / one rounding
+    ref_dense = work.view(dtype)[:dense.numel()]
+    tol = TOL32 if dtype == torch.float32 else TOL16[dtype]
+    assert rel(dense.float(), ref_dense.float().cpu().numpy()) < tol
+    assert rel(b1.float(), a1.float().cpu().numpy()) < tol and rel(b2.float(), a2.float().cpu().numpy()) < tol
+
+
+def test_more_lookups_than_one_fused_call(R):
+    """33 lookups in one graph take the pyramid route; the result equals 33 x one lookup's gradient."""
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    f1 = torch.randn((1, 32, 2, 48), generator=gen, device="cuda").requires_grad_(True)
+    f2 = torch.randn((1, 32, 2, 48), generator=gen, device="cuda").requires_grad_(True)
+    c = torch.from_numpy(O.synthetic_coords(1, 2, 48, seed=2)).cuda()
+    G = torch.randn((1, 36, 2, 48), generator=gen, device="cuda")
+    blk = R.CorrBlock1DHip(f1, f2)
+    sum((blk(c) * G).sum() for _ in range(33)).backward()
+    many1, many2 = f1.grad.clone(), f2.grad.clone()
+    f1.grad = f2.grad = None
+    blk = R.CorrBlock1DHip(f1, f2)
+    (blk(c) * G).sum().backward()
+    assert rel(many1, (33 * f1.grad).cpu().numpy()) < 1e-5 and rel(many2, (33 * f2.grad).cpu().numpy()) < 1e-5
+
+
 # ------------------------------------------------------------------ argument checking
 def test_argument_errors(R):
     f = torch.randn(1, 32, 2, 32, device="cuda")
