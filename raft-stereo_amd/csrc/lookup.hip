@@ -361,14 +361,67 @@ __global__ __launch_bounds__(LK_THREADS) void lookup_bwd_kernel(const float* __r
   }
 }
 
+// One lookup's contribution to one (level, pixel) gradient row held in LDS: the 2r+1 tap gradients g
+// spread over the window entries around xi (the level's coordinate).  The row belongs to the calling
+// thread alone; cell row[Wi] is a sink for entries outside the image.
+template <int R, int MODE>
+__device__ __forceinline__ void adjoint_accumulate(float* row, int Wi, float xi, float wm1,
+                                                   const float (&g)[2 * R + 1]) {
+  using WI = win_info<4, R, MODE>;
+  constexpr int NT = WI::NT, EXT = WI::EXT, NW = WI::NW;
+  const float xf = floorf(xi);
+  const float a = xi - xf;
+  const int wbase = rc_safe_int(xf) - R - EXT;
+  if (wbase + NW - 1 < 0 || wbase >= Wi) return;  // window outside the image
+
+  // tw[m] = gradient of window entry m (w2 of this level = wbase + m)
+  float tw[NW + 1];
+#pragma unroll
+  for (int m = 0; m <= NW; ++m) tw[m] = 0.f;
+  if constexpr (MODE == RC_COORD_EXACT) {
+    const float bw = 1.0f - a;
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+      tw[k] += g[k] * bw;
+      tw[k + 1] += g[k] * a;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+      int i0k;
+      float w0, w1w;
+      rc_gridsample_coords(xi, k - R, wm1, &i0k, &w0, &w1w);
+      const int dlt = i0k - (wbase + EXT + k);  // -1, 0 or +1 (the fp32 round trip can cross an integer)
+      const float a0 = g[k] * w0, a1 = g[k] * w1w;
+      tw[k] += dlt < 0 ? a0 : 0.f;
+      tw[k + 1] += dlt < 0 ? a1 : (dlt == 0 ? a0 : 0.f);
+      tw[k + 2] += dlt == 0 ? a1 : (dlt > 0 ? a0 : 0.f);
+      tw[k + 3] += dlt > 0 ? a1 : 0.f;
+    }
+  }
+  // branch-free: entries outside the image add their (unused) value to the sink cell row[Wi]
+  float cur[NW];
+  int idx[NW];
+#pragma unroll
+  for (int m = 0; m < NW; ++m) {
+    const int w2 = wbase + m;
+    idx[m] = (unsigned)w2 < (unsigned)Wi ? w2 : Wi;
+    cur[m] = row[idx[m]];
+  }
+#pragma unroll
+  for (int m = 0; m < NW; ++m) row[idx[m]] = cur[m] + tw[m];
+}
+
 // ---------------------------------------------------------------------------------------------
 // Fused adjoint of up to RC_MAX_FUSED_LOOKUPS lookups, written as the DENSE gradient of level 0:
 //   dC[bh][w1][w2] = 1/sqrt(D) * sum over lookups, levels i, taps of  2^-i * (tap gradient landing on w2 >> i)
 // in the feature type, rows `ldc` long (zero beyond W2).  This is what rc_lookup_bwd (once per
 // lookup, into the f32 gradient pyramid) followed by the unskew/fold step of rc_build_bwd
-// produces, without the pyramid: a workgroup owns TP pixels of one image row, accumulates all
-// lookups into per-level rows in LDS (f32, ds_add_f32), folds the levels and writes each dense
-// row once.  The 256 threads are 256/TP groups of TP pixels; group q takes lookups q, q + 256/TP, ...
+// produces, without the pyramid: a workgroup owns TP pixels of one image row and keeps their
+// per-level gradient rows in LDS (f32).  Thread (level i, pixel p) owns row (i, p): it walks all
+// lookups, adds each one's 2r+2 window entries into its row with plain LDS read-add-write (no
+// atomics: nobody else touches the row; the next lookup's gradient planes are in flight
+// meanwhile), then all threads fold the levels and write each dense row once.
 struct adj_lists {
   const float* coords[RC_MAX_FUSED_LOOKUPS];
   const float* gout[RC_MAX_FUSED_LOOKUPS];
@@ -377,84 +430,66 @@ struct adj_lists {
 struct adj_dims {
   int B, H, W1, W2, L, ldc, n, cc;
   int width[RC_MAX_LEVELS];
-  int pitch[RC_MAX_LEVELS];  // LDS row pitch of level i (floats)
+  int pitch[RC_MAX_LEVELS];  // LDS row pitch of level i (floats): odd and > width (cell `width` is a sink)
   int base[RC_MAX_LEVELS];   // LDS offset of level i = TP * sum of the lower pitches
 };
 
+typedef const float __attribute__((address_space(1)))* rc_gptr;  // a pointer known to be global memory
+
 template <typename T, int R, int MODE, int TP>
-__global__ __launch_bounds__(256) void adjoint_dense_kernel(adj_lists lists, adj_dims d, T* __restrict__ dC,
-                                                            float scale) {
+__global__ __launch_bounds__(RC_MAX_LEVELS * TP) void adjoint_dense_kernel(adj_lists lists, adj_dims d,
+                                                                           T* __restrict__ dC, float scale) {
   using WI = win_info<4, R, MODE>;
   constexpr int NT = WI::NT, EXT = WI::EXT, NW = WI::NW;
-  constexpr int NG = 256 / TP;
+  constexpr int NTHR = RC_MAX_LEVELS * TP;
   extern __shared__ __attribute__((aligned(16))) float acc[];
-  __shared__ const float* s_coords[RC_MAX_FUSED_LOOKUPS];
-  __shared__ const float* s_gout[RC_MAX_FUSED_LOOKUPS];
 
   const int tiles = (d.W1 + TP - 1) / TP;
   const int bh = blockIdx.x / tiles;
   const int c0 = (blockIdx.x - bh * tiles) * TP;
   const int b = bh / d.H, h = bh - b * d.H;
-  const int p = threadIdx.x % TP, q = threadIdx.x / TP;
+  const int p = threadIdx.x % TP, lvl = threadIdx.x / TP;
   const int w1 = c0 + p;
   const int64_t HW = (int64_t)d.H * d.W1;
-  const int total = d.base[d.L - 1] + TP * d.pitch[d.L - 1];  // floats of LDS in use
+  const int L = d.L;
+  const int total = d.base[L - 1] + TP * d.pitch[L - 1];  // floats of LDS in use
 
-  if (threadIdx.x < RC_MAX_FUSED_LOOKUPS) {
-    s_coords[threadIdx.x] = lists.coords[threadIdx.x];
-    s_gout[threadIdx.x] = lists.gout[threadIdx.x];
-  }
-  for (int e = threadIdx.x; e < total; e += 256) acc[e] = 0.f;
+  typedef float f4z __attribute__((ext_vector_type(4)));
+  for (int e = threadIdx.x; e < (total + 3) >> 2; e += NTHR) reinterpret_cast<f4z*>(acc)[e] = (f4z){0.f, 0.f, 0.f, 0.f};
   __syncthreads();
 
-  if (w1 < d.W1) {
-    for (int t = q; t < d.n; t += NG) {
-      const float x = s_coords[t][((int64_t)b * d.cc) * HW + (int64_t)h * d.W1 + w1];
-      const float* gp = s_gout[t] + ((int64_t)b * d.L * NT) * HW + (int64_t)h * d.W1 + w1;
-      for (int i = 0; i < d.L; ++i) {
-        const int Wi = d.width[i];
+  if (w1 < d.W1 && lvl < L) {
+    const int Wi = d.width[lvl];
+    const float inv = 1.0f / (float)(1 << lvl);
+    const float wm1 = (float)(Wi - 1);
+    float* row = acc + d.base[lvl] + p * d.pitch[lvl];
+    const int64_t coff = ((int64_t)b * d.cc) * HW + (int64_t)h * d.W1 + w1;
+    const int64_t goff = (((int64_t)b * L + lvl) * NT) * HW + (int64_t)h * d.W1 + w1;
+    // PD lookups' planes are in flight at any time: with the pixel tile bounded by LDS only a few
+    // waves fit on a CU, so the latency has to be covered from inside the wave
+    constexpr int PD = 4;
+    float xs[PD], gs[PD][NT];
+    auto fetch = [&](int t, int slot) {  // t is block-uniform: the list entries come through scalar loads
+      xs[slot] = ((rc_gptr)lists.coords[t])[coff];
+      rc_gptr gp = ((rc_gptr)lists.gout[t]) + goff;
+#pragma unroll
+      for (int k = 0; k < NT; ++k) gs[slot][k] = gp[(int64_t)k * HW];
+    };
+    // every fetch is unconditional (past the end it re-reads the last lookup, a cache hit): a load
+    // under a branch would make the compiler wait for all loads at every join
+    const int last = d.n - 1;
+#pragma unroll
+    for (int j = 0; j < PD; ++j) fetch(min(j, last), j);
+    for (int t0 = 0; t0 < d.n; t0 += PD) {
+#pragma unroll
+      for (int j = 0; j < PD; ++j) {
+        const int t = t0 + j;
+        const float x = xs[j];
         float g[NT];
 #pragma unroll
-        for (int k = 0; k < NT; ++k) g[k] = gp[((int64_t)i * NT + k) * HW];
-        const float xi = x * (1.0f / (float)(1 << i));
-        const float xf = floorf(xi);
-        const float a = xi - xf;
-        const int wbase = rc_safe_int(xf) - R - EXT;
-        if (wbase + NW - 1 < 0 || wbase >= Wi) continue;  // window outside the image
-
-        // tw[m] = gradient of window entry m (w2 of level i = wbase + m)
-        float tw[NW + 1];
-#pragma unroll
-        for (int m = 0; m <= NW; ++m) tw[m] = 0.f;
-        if constexpr (MODE == RC_COORD_EXACT) {
-          const float bw = 1.0f - a;
-#pragma unroll
-          for (int k = 0; k < NT; ++k) {
-            tw[k] += g[k] * bw;
-            tw[k + 1] += g[k] * a;
-          }
-        } else {
-          const float wm1 = (float)(Wi - 1);
-#pragma unroll
-          for (int k = 0; k < NT; ++k) {
-            int i0k;
-            float w0, w1w;
-            rc_gridsample_coords(xi, k - R, wm1, &i0k, &w0, &w1w);
-            const int dlt = i0k - (wbase + EXT + k);  // -1, 0 or +1 (the fp32 round trip can cross an integer)
-            const float a0 = g[k] * w0, a1 = g[k] * w1w;
-            tw[k] += dlt < 0 ? a0 : 0.f;
-            tw[k + 1] += dlt < 0 ? a1 : (dlt == 0 ? a0 : 0.f);
-            tw[k + 2] += dlt == 0 ? a1 : (dlt > 0 ? a0 : 0.f);
-            tw[k + 3] += dlt > 0 ? a1 : 0.f;
-          }
-        }
-        float* row = acc + d.base[i] + p * d.pitch[i];
-#pragma unroll
-        for (int m = 0; m < NW; ++m) {
-          const int w2 = wbase + m;
-          const bool ok = (unsigned)w2 < (unsigned)Wi;
-          atomicAdd(row + (ok ? w2 : 0), ok ? tw[m] : 0.f);  // branch-free: out-of-image entries add 0 to cell 0
-        }
+        for (int k = 0; k < NT; ++k) g[k] = gs[j][k];
+        fetch(min(t + PD, last), j);
+        if (t < d.n) adjoint_accumulate<R, MODE>(row, Wi, x * inv, wm1, g);
       }
     }
   }
@@ -463,20 +498,28 @@ __global__ __launch_bounds__(256) void adjoint_dense_kernel(adj_lists lists, adj
   // fold the levels (a pooled cell spreads 2^-i of its gradient over its 2^i children) and write the
   // dense rows, 8 consecutive w2 per thread
   const int segs = d.ldc >> 3;
-  for (int e = threadIdx.x; e < TP * segs; e += 256) {
+  for (int e = threadIdx.x; e < TP * segs; e += NTHR) {
     const int pp = e / segs, w20 = (e - pp * segs) * 8;
     if (c0 + pp >= d.W1) continue;
+    // 8 + 4 + 2 + 1 independent LDS reads; levels the pyramid does not have come with width 0
+    float part[RC_MAX_LEVELS][8];
+#pragma unroll
+    for (int i = 0; i < RC_MAX_LEVELS; ++i) {
+      const float* rw = acc + d.base[i] + pp * d.pitch[i];
+      const int wi0 = w20 >> i;
+      const float wgt = scale / (float)(1 << i);
+#pragma unroll
+      for (int r = 0; r < (8 >> i); ++r) {
+        const int wi = wi0 + r;
+        const float val = rw[min(wi, d.width[i])];
+        part[i][r] = wi < d.width[i] ? wgt * val : 0.f;
+      }
+    }
     float v[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      const int w2 = w20 + r;
-      float sum = 0.f, wgt = scale;
-      for (int i = 0; i < d.L; ++i) {
-        const int wi = w2 >> i;
-        if (wi < d.width[i]) sum += wgt * acc[d.base[i] + pp * d.pitch[i] + wi];
-        wgt *= 0.5f;
-      }
-      v[r] = w2 < d.W2 ? sum : 0.f;
+      const float sum = ((part[0][r] + part[1][r >> 1]) + part[2][r >> 2]) + part[3][r >> 3];
+      v[r] = w20 + r < d.W2 ? sum : 0.f;
     }
     T* dst = dC + ((int64_t)bh * d.W1 + c0 + pp) * d.ldc + w20;
     if constexpr (sizeof(T) == 4) {
@@ -494,16 +537,16 @@ __global__ __launch_bounds__(256) void adjoint_dense_kernel(adj_lists lists, adj
 
 template <typename T, int R, int MODE>
 int launch_adjoint_dense(const adj_lists& lists, adj_dims d, void* dC, float scale, hipStream_t st) {
-  // the largest pixel tile whose per-level rows fit in 64 KiB of LDS
+  // the largest pixel tile whose per-level rows fit in 80 KiB of LDS
   int sum_pitch = 0;
   for (int i = 0; i < d.L; ++i) {
-    d.pitch[i] = (d.width[i] + 31) / 32 * 32;
+    d.pitch[i] = (d.width[i] + 1) | 1;
     sum_pitch += d.pitch[i];
   }
   int tp = 64;
-  while (tp > 8 && (int64_t)tp * sum_pitch * 4 > 64 * 1024) tp >>= 1;
-  const int64_t lds = (int64_t)tp * sum_pitch * 4;
-  RC_REQUIRE(lds <= 160 * 1024 - 1024, RC_EUNSUPPORTED, "W2=%d is too wide for the fused adjoint", d.W2);
+  while (tp > 8 && (int64_t)tp * sum_pitch * 4 > 80 * 1024) tp >>= 1;
+  const int64_t lds = ((int64_t)tp * sum_pitch * 4 + 15) & ~(int64_t)15;
+  RC_REQUIRE(lds <= 159 * 1024, RC_EUNSUPPORTED, "W2=%d is too wide for the fused adjoint", d.W2);
   int off = 0;
   for (int i = 0; i < d.L; ++i) {
     d.base[i] = off;
@@ -528,8 +571,8 @@ int launch_adjoint_dense(const adj_lists& lists, adj_dims d, void* dC, float sca
       }                                                                                                   \
       attr_set[dev] = true;                                                                               \
     }                                                                                                     \
-    hipLaunchKernelGGL((adjoint_dense_kernel<T, R, MODE, TPV>), dim3((unsigned)blocks), dim3(256), (size_t)lds, \
-                       st, lists, d, (T*)dC, scale);                                                      \
+    hipLaunchKernelGGL((adjoint_dense_kernel<T, R, MODE, TPV>), dim3((unsigned)blocks),                   \
+                       dim3(RC_MAX_LEVELS * TPV), (size_t)lds, st, lists, d, (T*)dC, scale);              \
     break;                                                                                                \
   }
   switch (tp) {
@@ -720,7 +763,11 @@ extern "C" int rc_lookup_bwd_dense(const float* const* coords_list, const float*
   d.ldc = (int)((glay->W2 + 31) / 32 * 32);
   d.n = n_lookups;
   d.cc = coords_channels;
-  for (int i = 0; i < RC_MAX_LEVELS; ++i) { d.width[i] = glay->width[i]; d.pitch[i] = 0; d.base[i] = 0; }
+  for (int i = 0; i < RC_MAX_LEVELS; ++i) {
+    d.width[i] = i < glay->L ? glay->width[i] : 0;  // width 0: the fold skips the level
+    d.pitch[i] = 0;
+    d.base[i] = 0;
+  }
   const float scale = (float)(1.0 / sqrt((double)D));
   hipStream_t st = (hipStream_t)stream;
   switch (out_dtype) {
