@@ -90,6 +90,7 @@ class _BuildFn(torch.autograd.Function):
         block._build(fmap1, fmap2)
         ctx.block = block
         ctx.save_for_backward(fmap1, fmap2)
+        ctx.set_materialize_grads(False)    # the token's gradient carries nothing: lookups return None for it
         return torch.zeros(1, dtype=torch.float32, device=fmap1.device)
 
     @staticmethod
@@ -146,7 +147,7 @@ class _LookupFn(torch.autograd.Function):
         # takes all (coords, grad_out) pairs in one fused call
         (coords,) = ctx.saved_tensors
         ctx.block._pending.append((coords, grad_out.float().contiguous()))        # core/corr.py:27
-        return torch.zeros(1, dtype=torch.float32, device=coords.device), None, None
+        return None, None, None     # autograd still runs the build's backward once all lookups have
 
 
 class CorrBlock1DHip:
