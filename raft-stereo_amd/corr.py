@@ -103,21 +103,32 @@ class _BuildFn(torch.autograd.Function):
         df1, df2 = torch.empty_like(fmap1), torch.empty_like(fmap2)
         lay = block.grad_layout
         dev = fmap1.device
+        nmax = _lib.RC_MAX_FUSED_LOOKUPS
         with torch.cuda.device(dev):
             st = _stream(dev)
-            if len(pending) <= _lib.RC_MAX_FUSED_LOOKUPS:
-                # one fused adjoint of all lookups -> dense gradient of level 0 -> two contractions
+            if len(pending) <= nmax or block.volume is None:
+                # one fused adjoint of all lookups -> dense gradient of level 0 -> two contractions.
+                # (alt_hip has no pyramid to mirror, so more than nmax lookups go in chunks whose
+                # feature gradients are summed in fp32.)
                 ld = int(lib.rc_dense_grad_ld(lay))
                 dense = torch.empty(block.B * block.H * block.W1 * ld, dtype=fmap1.dtype, device=dev)
-                n = len(pending)
-                cl = (ctypes.c_void_p * n)(*[c.data_ptr() for c, _ in pending])
-                gl = (ctypes.c_void_p * n)(*[g.data_ptr() for _, g in pending])
-                check(lib.rc_lookup_bwd_dense(cl, gl, n, pending[0][0].shape[1], dense.data_ptr(), lay, block.D,
-                                              block.in_dtype, block.radius, block.coord_mode, st),
-                      "rc_lookup_bwd_dense")
-                check(lib.rc_build_bwd_dense(dense.data_ptr(), lay, fmap1.data_ptr(), fmap2.data_ptr(),
-                                             df1.data_ptr(), df2.data_ptr(), block.D, block.in_dtype, st),
-                      "rc_build_bwd_dense")
+                chunks = [pending[k:k + nmax] for k in range(0, len(pending), nmax)]
+                sum1 = sum2 = None
+                for part in chunks:
+                    n = len(part)
+                    cl = (ctypes.c_void_p * n)(*[c.data_ptr() for c, _ in part])
+                    gl = (ctypes.c_void_p * n)(*[g.data_ptr() for _, g in part])
+                    check(lib.rc_lookup_bwd_dense(cl, gl, n, part[0][0].shape[1], dense.data_ptr(), lay, block.D,
+                                                  block.in_dtype, block.radius, block.coord_mode, st),
+                          "rc_lookup_bwd_dense")
+                    check(lib.rc_build_bwd_dense(dense.data_ptr(), lay, fmap1.data_ptr(), fmap2.data_ptr(),
+                                                 df1.data_ptr(), df2.data_ptr(), block.D, block.in_dtype, st),
+                          "rc_build_bwd_dense")
+                    if len(chunks) > 1:
+                        sum1 = df1.to(torch.float32, copy=True) if sum1 is None else sum1.add_(df1)
+                        sum2 = df2.to(torch.float32, copy=True) if sum2 is None else sum2.add_(df2)
+                if len(chunks) > 1:
+                    df1, df2 = sum1.to(fmap1.dtype), sum2.to(fmap2.dtype)
             else:
                 # more lookups than one fused call takes: accumulate into a float gradient pyramid
                 gvol = torch.zeros(lay.total, dtype=torch.float32, device=dev)
@@ -233,7 +244,9 @@ class CorrBlock1DHip:
 class AltCorrBlock1DHip:
     """`alt_hip`: same outputs as CorrBlock1DHip without ever building the volume
     (PytorchAlternateCorrBlock1D, core/corr.py:64-107).  Like the reg path it samples along x
-    only: coords channel 1 is the pixel's own row in RAFT-Stereo (core/raft_stereo.py:120)."""
+    only: coords channel 1 is the pixel's own row in RAFT-Stereo (core/raft_stereo.py:120).
+    Differentiable w.r.t. fmap1/fmap2 like the reference's (which relies on autograd through
+    grid_sample): the backward is the fused adjoint + two contractions of the reg path."""
 
     def __init__(self, fmap1, fmap2, num_levels=4, radius=4, coord_mode=None):
         B, D, H, W1, W2 = _check_fmaps(fmap1, fmap2, num_levels, radius)
@@ -248,23 +261,40 @@ class AltCorrBlock1DHip:
         self.coord_mode = COORD_MODES[coord_mode]
         self.layout = AltLayout()
         check(lib.rc_alt_layout_init(B, D, H, W1, W2, num_levels, self.layout), "rc_alt_layout_init")
-        fmap1, fmap2 = fmap1.detach().contiguous(), fmap2.detach().contiguous()
+        # the adjoint of the alt lookups is the adjoint of the reg lookups (same function of the
+        # feature maps): the backward needs only the geometry of a pyramid, never its memory
+        self.grad_layout = Layout()
+        check(lib.rc_pyramid_layout(B, H, W1, W2, num_levels, _lib.RC_F32, self.grad_layout), "rc_pyramid_layout")
+        self.volume = None
+        self._pending = []
+        self._out_shape = (B, num_levels * (2 * radius + 1), H, W1)
+        fmap1, fmap2 = fmap1.contiguous(), fmap2.contiguous()
+        if torch.is_grad_enabled() and (fmap1.requires_grad or fmap2.requires_grad):
+            self._token = _BuildFn.apply(fmap1, fmap2, self)
+        else:
+            self._token = None
+            self._build(fmap1.detach(), fmap2.detach())
+
+    def _build(self, fmap1, fmap2):
         with torch.cuda.device(self.device):
             self.f1t = torch.empty(self.layout.f1_elems, dtype=fmap1.dtype, device=self.device)
             self.f2t = torch.empty(self.layout.f2_elems, dtype=fmap1.dtype, device=self.device)
             check(lib.rc_alt_prepare(fmap1.data_ptr(), fmap2.data_ptr(), self.f1t.data_ptr(), self.f2t.data_ptr(),
                                      self.layout, self.in_dtype, _stream(self.device)), "rc_alt_prepare")
 
-    def __call__(self, coords):
-        coords = _check_coords(coords, self.B, self.H, self.W1, self.device)
-        nt = 2 * self.radius + 1
+    def _lookup(self, coords):
         with torch.cuda.device(self.device):
-            out = torch.empty((self.B, self.num_levels * nt, self.H, self.W1), dtype=torch.float32,
-                              device=self.device)
+            out = torch.empty(self._out_shape, dtype=torch.float32, device=self.device)
             check(lib.rc_alt_fwd(self.f1t.data_ptr(), self.f2t.data_ptr(), self.layout, self.in_dtype,
                                  coords.data_ptr(), coords.shape[1], out.data_ptr(), self.radius,
                                  self.coord_mode, _stream(self.device)), "rc_alt_fwd")
         return out
+
+    def __call__(self, coords):
+        coords = _check_coords(coords, self.B, self.H, self.W1, self.device)
+        if self._token is not None and torch.is_grad_enabled():
+            return _LookupFn.apply(self._token, coords, self)
+        return self._lookup(coords)
 
 
 class CorrSamplerHip(torch.autograd.Function):

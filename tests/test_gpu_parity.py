@@ -104,6 +104,22 @@ def test_alt_fp32_matches_reference_reg(R, golden, case, kind):
     assert rel(out, g[f"alt_{kind}"]) < 5e-5
 
 
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_alt_backward_fp32_matches_reference_autograd(R, golden, case):
+    """alt_hip is the same function of the feature maps as reg, so the reference's autograd
+    gradients of the reg path pin its backward too (core/corr.py:64-107 relies on autograd)."""
+    g = golden(case)
+    L, r = int(g["L"]), int(g["r"])
+    f1 = dev(g["f1"]).requires_grad_(True)
+    f2 = dev(g["f2"]).requires_grad_(True)
+    blk = R.AltCorrBlock1DHip(f1, f2, num_levels=L, radius=r)
+    outs = [blk(dev(g[f"coords_{k}"])) for k in KINDS]
+    assert all(o.requires_grad for o in outs)
+    sum((o * dev(g[f"gout_{k}"])).sum() for o, k in zip(outs, KINDS)).backward()
+    assert rel(f1.grad, g["df1_multi"]) < TOL32
+    assert rel(f2.grad, g["df2_multi"]) < TOL32
+
+
 # ------------------------------------------------------------------ MFMA kernel vs the naive kernel
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("shape", [(2, 256, 3, 312, 312), (1, 96, 2, 70, 131), (1, 256, 2, 200, 45),
@@ -301,6 +317,22 @@ def test_more_lookups_than_one_fused_call(R):
     blk = R.CorrBlock1DHip(f1, f2)
     (blk(c) * G).sum().backward()
     assert rel(many1, (33 * f1.grad).cpu().numpy()) < 1e-5 and rel(many2, (33 * f2.grad).cpu().numpy()) < 1e-5
+
+
+def test_alt_more_lookups_than_one_fused_call(R):
+    """alt_hip has no pyramid: 70 lookups go through three fused calls whose gradients are summed."""
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    f1 = torch.randn((1, 32, 2, 48), generator=gen, device="cuda").requires_grad_(True)
+    f2 = torch.randn((1, 32, 2, 48), generator=gen, device="cuda").requires_grad_(True)
+    c = torch.from_numpy(O.synthetic_coords(1, 2, 48, seed=3)).cuda()
+    G = torch.randn((1, 36, 2, 48), generator=gen, device="cuda")
+    blk = R.AltCorrBlock1DHip(f1, f2)
+    sum((blk(c) * G).sum() for _ in range(70)).backward()
+    many1, many2 = f1.grad.clone(), f2.grad.clone()
+    f1.grad = f2.grad = None
+    blk = R.CorrBlock1DHip(f1, f2)
+    (blk(c) * G).sum().backward()
+    assert rel(many1, (70 * f1.grad).cpu().numpy()) < 1e-5 and rel(many2, (70 * f2.grad).cpu().numpy()) < 1e-5
 
 
 # ------------------------------------------------------------------ argument checking
