@@ -3,15 +3,18 @@
 // Replaces core/corr.py:64-107 (PytorchAlternateCorrBlock1D) of the reference, which runs 36
 // full-feature grid_samples per GRU iteration and re-pools fmap2 on every call.
 //
-// rc_alt_prepare (once per image pair) writes channel-last copies: f1t [B,H,W1,Dp] and the
-// pooled f2 pyramid f2t_i [B,H,W2>>i,Dp], so a pixel's feature vector is one contiguous run and
-// MFMA operands are K-major without any transposition.
+// rc_alt_prepare (once per image pair) writes the working copies f1t and the pooled f2 pyramid
+// f2t_i in MFMA-fragment order: positions in blocks of 16, channels in chunks of KCH (32 for
+// 16-bit, 16 for f32); chunk kc of position block pb is the 64 x 16-byte operand of one MFMA,
+// lane (g, li) = channels kc*KCH + [g*KCH/4, (g+1)*KCH/4) of position 16*pb + li:
+//   element offset = ((row*nblk + pb)*nkc + kc)*64*EL + (g*16 + li)*EL + e,  EL = 16 B / elemsize.
+// An operand load is then one contiguous 1 KiB run per wave instruction (8 cache lines instead of 64).
 // rc_alt_fwd (every iteration): a wave owns 16 consecutive pixels of one image row.  Per level it
 // takes the union of the pixels' tap windows, and for each 16-wide block of right-image
 // positions in it forms the 16x16 product tile  f2t_i[block] . f1t[pixels]^T  on the matrix
-// cores (K = Dp); MFMA rows are w2, so a lane holds 4 consecutive w2 of one pixel and folds them
-// straight into that pixel's 2r+1 interpolated taps.  With locally smooth disparity a level
-// needs 1-3 blocks; arbitrary coords stay correct, only slower.
+// cores (K = Dp); MFMA rows are w2, so a lane holds 4 consecutive w2 of one pixel; it drops those
+// inside the pixel's own window into LDS, from where the pixel's 2r+1 taps are interpolated.
+// With locally smooth disparity a level needs 1-3 blocks; arbitrary coords stay correct, only slower.
 #include "rc_common.h"
 
 #include <math.h>
@@ -49,13 +52,16 @@ alt_dev_layout to_dev(const rc_alt_layout* a) {
   return d;
 }
 
-// NCHW [B,D,H,W] -> channel-last [B,H,W>>level,Dp], averaging 2^level source columns (pairwise
-// tree, the order of the avg_pool2d chain, corr.py:104) and zero padding D..Dp.
+// NCHW [B,D,H,W] -> fragment order (see the file header) of level `level`: averages 2^level source
+// columns (pairwise tree, the order of the avg_pool2d chain, corr.py:104); zero beyond the level's
+// width (blocks are padded to 16 positions) and beyond D (padded to Dp).
 template <typename T>
-__global__ __launch_bounds__(256) void to_channel_last_kernel(const T* __restrict__ src, T* __restrict__ dst,
-                                                              int D, int Dp, int H, int W, int level) {
+__global__ __launch_bounds__(256) void to_fragments_kernel(const T* __restrict__ src, T* __restrict__ dst,
+                                                           int D, int Dp, int H, int W, int level) {
+  constexpr int EL = 16 / (int)sizeof(T), KCH = 4 * EL;
   __shared__ float tile[64][65];
   const int Wl = W >> level;
+  const int nblk = (Wl + 15) >> 4, nkc = Dp / KCH;
   const int w0 = blockIdx.x * 64, d0 = blockIdx.y * 64;
   const int bh = blockIdx.z, b = bh / H, h = bh - b * H;
   {
@@ -79,70 +85,76 @@ __global__ __launch_bounds__(256) void to_channel_last_kernel(const T* __restric
     }
   }
   __syncthreads();
-  {
-    const int dc = threadIdx.x & 63, wr = threadIdx.x >> 6;
-    const int d = d0 + dc;
-    for (int ww = wr; ww < 64; ww += 4) {
-      const int w = w0 + ww;
-      if (w < Wl && d < Dp) dst[((int64_t)bh * Wl + w) * Dp + d] = rc_from_float<T>(tile[dc][ww]);
-    }
+  // one 16-byte fragment piece per thread and step; consecutive threads write consecutive pieces
+  constexpr int KPT = 64 / KCH;  // channel chunks per tile
+  for (int f = threadIdx.x; f < 4 * KPT * 64; f += 256) {
+    const int li = f & 15, g = (f >> 4) & 3, kcl = (f >> 6) % KPT, blk = (f >> 6) / KPT;
+    const int pb = (w0 >> 4) + blk, kc = d0 / KCH + kcl;
+    if (pb >= nblk || kc >= nkc) continue;
+    __attribute__((aligned(16))) T v[EL];
+#pragma unroll
+    for (int e = 0; e < EL; ++e) v[e] = rc_from_float<T>(tile[kcl * KCH + g * EL + e][blk * 16 + li]);
+    T* q = dst + ((((int64_t)bh * nblk + pb) * nkc + kc) * 64 + g * 16 + li) * EL;
+    *reinterpret_cast<uint4*>(q) = *reinterpret_cast<const uint4*>(v);
   }
 }
 
-template <typename T, int R, int MODE>
+// FULL: Dp == DMAX, every operand load unconditional (the real model's D = 256).
+template <typename T, int R, int MODE, bool FULL>
 __global__ __launch_bounds__(256) void alt_fwd_kernel(const T* __restrict__ f1t, const T* __restrict__ f2t,
                                                       alt_dev_layout lay, const float* __restrict__ coords,
                                                       int coords_channels, float* __restrict__ out,
-                                                      float scale, int groups_per_row, int n_groups) {
+                                                      float scale, int blocks_per_row, int n_rows) {
   constexpr bool IS16 = !std::is_same<T, float>::value;
   constexpr int NT = 2 * R + 1;
-  constexpr int KCH = IS16 ? 32 : 16;          // K elements consumed per operand load
+  constexpr int EXT = MODE == RC_COORD_GRIDSAMPLE ? 1 : 0;  // grid_sample's fp32 round trip can move a tap by one
+  constexpr int NS = NT + 1 + 2 * EXT;                      // correlation values a pixel's taps can touch
+  constexpr int PITCH = NS | 1;
+  constexpr int EL = 16 / (int)sizeof(T);
+  constexpr int KCH = 4 * EL;                               // K elements consumed per operand load
   constexpr int NKC = DMAX / KCH;
+  // a pixel's window of correlation values, per wave and level: slot j <-> w2 = base + j
+  __shared__ float win[4][RC_MAX_LEVELS][16][PITCH];
+
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, li = lane & 15;
-  const int grp = blockIdx.x * 4 + wave;        // (row, 16-pixel group)
-  if (grp >= n_groups) return;                  // wave-uniform
-  const int bh = grp / groups_per_row;
-  const int w1 = (grp - bh * groups_per_row) * 16 + li;
+  // A workgroup owns 64 consecutive pixels of one image row.  Workgroup ids that agree mod 8 run on
+  // the same XCD: they get the same rows, so a row of fmap2 goes through one L2 only.
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int bh = (slot / blocks_per_row) * 8 + xcd;
+  const int pb1 = (slot % blocks_per_row) * 4 + wave;  // the wave's block of 16 pixels
+  const int w1 = pb1 * 16 + li;
+  if (bh >= n_rows || pb1 * 16 >= lay.W1) return;  // wave-uniform
   const int b = bh / lay.H, h = bh - b * lay.H;
   const bool live = w1 < lay.W1;
+  const int w1c = live ? w1 : lay.W1 - 1;
   const int64_t HW = (int64_t)lay.H * lay.W1;
-  const int nkc = lay.Dp / KCH;
+  const int nkc = FULL ? NKC : lay.Dp / KCH;
+  const int64_t blk_elems = (int64_t)nkc * 64 * EL;  // one block of 16 positions, all channels
 
-  // this pixel's feature vector as the MFMA B operand (columns = pixels)
+  // the pixels' feature vectors as MFMA B operands (columns = pixels)
   uint4 bfrag[NKC];
   {
-    const T* p = f1t + ((int64_t)bh * lay.W1 + (live ? w1 : 0)) * lay.Dp + (IS16 ? 8 : 4) * g;
+    const T* p = f1t + ((int64_t)bh * ((lay.W1 + 15) >> 4) + pb1) * blk_elems + lane * EL;
 #pragma unroll
-    for (int kc = 0; kc < NKC; ++kc)
-      bfrag[kc] = (live && kc < nkc) ? *reinterpret_cast<const uint4*>(p + kc * KCH) : make_uint4(0, 0, 0, 0);
+    for (int kc = 0; kc < NKC; ++kc) {
+      if (FULL) bfrag[kc] = *reinterpret_cast<const uint4*>(p + kc * 64 * EL);
+      else bfrag[kc] = kc < nkc ? *reinterpret_cast<const uint4*>(p + kc * 64 * EL) : make_uint4(0, 0, 0, 0);
+    }
   }
-  const float x = live ? coords[((int64_t)b * coords_channels) * HW + (int64_t)h * lay.W1 + w1] : 0.f;
+  const float x = coords[((int64_t)b * coords_channels) * HW + (int64_t)h * lay.W1 + w1c];
 
   float inv = 1.0f;
   for (int i = 0; i < lay.L; ++i) {
     const int Wi = lay.width[i];
     const float xi = x * inv;
     inv *= 0.5f;
-    int i0[NT];
-    float w0[NT], wt1[NT];
-    int lo = 1 << 30, hi = -(1 << 30);
-    if (MODE == RC_COORD_EXACT) {
-      const float xf = floorf(xi);
-      const float a = xi - xf;
-      const int base = rc_safe_int(xf) - R;
-#pragma unroll
-      for (int k = 0; k < NT; ++k) { i0[k] = base + k; w0[k] = 1.0f - a; wt1[k] = a; }
-    } else {
-      const float wm1 = (float)(Wi - 1);
-#pragma unroll
-      for (int k = 0; k < NT; ++k) rc_gridsample_coords(xi, k - R, wm1, &i0[k], &w0[k], &wt1[k]);
-    }
-    if (live) {
-#pragma unroll
-      for (int k = 0; k < NT; ++k) { lo = min(lo, i0[k]); hi = max(hi, i0[k] + 1); }
-    }
+    const float xf = floorf(xi);
+    const int base = rc_safe_int(xf) - R - EXT;
+    float* mywin = &win[wave][i][li][0];
+
     // union of the 16 pixels' windows (all 64 lanes take part; the 4 groups hold copies)
+    int lo = live ? base : (1 << 30), hi = live ? base + NS - 1 : -(1 << 30);
 #pragma unroll
     for (int o = 1; o < 16; o <<= 1) {
       lo = min(lo, __shfl_xor(lo, o));
@@ -151,48 +163,57 @@ __global__ __launch_bounds__(256) void alt_fwd_kernel(const T* __restrict__ f1t,
     lo = max(lo, 0);
     hi = min(hi, Wi - 1);
 
-    float o_[NT];
-#pragma unroll
-    for (int k = 0; k < NT; ++k) o_[k] = 0.f;
-
-    const T* f2l = f2t + lay.f2_offset[i] + ((int64_t)bh * Wi) * lay.Dp;
+    const T* f2l = f2t + lay.f2_offset[i] + ((int64_t)bh * ((Wi + 15) >> 4)) * blk_elems + lane * EL;
     for (int cb = lo >> 4; cb <= (hi >> 4); ++cb) {  // empty when lo > hi
-      const int wrow = cb * 16 + li;
-      const bool rok = wrow < Wi;
-      const T* ap = f2l + (int64_t)(rok ? wrow : 0) * lay.Dp + (IS16 ? 8 : 4) * g;
+      // 16 right-image positions x 16 pixels on the matrix cores
+      const T* ap = f2l + cb * blk_elems;
+      uint4 av[NKC];
+#pragma unroll
+      for (int kc = 0; kc < NKC; ++kc)
+        if (FULL || kc < nkc) av[kc] = *reinterpret_cast<const uint4*>(ap + kc * 64 * EL);
       f4v acc = (f4v)(0.f);
 #pragma unroll
       for (int kc = 0; kc < NKC; ++kc) {
-        if (kc < nkc) {
-          const uint4 av = rok ? *reinterpret_cast<const uint4*>(ap + kc * KCH) : make_uint4(0, 0, 0, 0);
+        if (FULL || kc < nkc) {
           if constexpr (IS16) {
-            acc = mfma16<T>(__builtin_bit_cast(s8v, av), __builtin_bit_cast(s8v, bfrag[kc]), acc);
+            acc = mfma16<T>(__builtin_bit_cast(s8v, av[kc]), __builtin_bit_cast(s8v, bfrag[kc]), acc);
           } else {
-            const f4v a4 = __builtin_bit_cast(f4v, av), b4 = __builtin_bit_cast(f4v, bfrag[kc]);
+            const f4v a4 = __builtin_bit_cast(f4v, av[kc]), b4 = __builtin_bit_cast(f4v, bfrag[kc]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[e], b4[e], acc, 0, 0, 0);
           }
         }
       }
-      // lane holds C[w2 = cb*16 + 4g + r][this pixel]; fold into the interpolated taps
+      // lane holds C[w2 = cb*16 + 4g + r][this pixel]: keep what falls into the pixel's own window
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int w2 = cb * 16 + 4 * g + r;
-        const float v = acc[r];
-#pragma unroll
-        for (int k = 0; k < NT; ++k) {
-          const float wgt = (w2 == i0[k] ? w0[k] : 0.f) + (w2 == i0[k] + 1 ? wt1[k] : 0.f);
-          o_[k] = fmaf(wgt, v, o_[k]);
-        }
+        const int j = w2 - base;
+        if ((unsigned)j < (unsigned)NS && w2 < Wi) mywin[j] = acc[r];
       }
     }
-    // sum the four w2 sub-ranges held by the lane groups, then spread the stores over the groups
+    // the four lane groups of a pixel exchange through LDS: one wave, in-order LDS, no workgroup barrier
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // lane group g interpolates taps g, g+4, g+8, ...; a tap position outside the image counts 0
 #pragma unroll
-    for (int k = 0; k < NT; ++k) {
-      float s = o_[k];
-      s += __shfl_xor(s, 16);
-      s += __shfl_xor(s, 32);
-      if (live && (k & 3) == g) out[((int64_t)b * lay.L * NT + i * NT + k) * HW + (int64_t)h * lay.W1 + w1] = s * scale;
+    for (int k0 = 0; k0 < NT; k0 += 4) {
+      const int k = k0 + g;
+      int t0;
+      float wa, wb;
+      if (MODE == RC_COORD_EXACT) {
+        t0 = base + k;
+        wb = xi - xf;
+        wa = 1.0f - wb;
+      } else {
+        rc_gridsample_coords(xi, k - R, (float)(Wi - 1), &t0, &wa, &wb);
+      }
+      const int j0 = min(max(t0 - base, 0), NS - 2);
+      const float v0 = mywin[j0], v1 = mywin[j0 + 1];
+      const float s = ((unsigned)t0 < (unsigned)Wi ? wa * v0 : 0.f) + ((unsigned)(t0 + 1) < (unsigned)Wi ? wb * v1 : 0.f);
+      if (live && k < NT) out[((int64_t)b * lay.L * NT + i * NT + k) * HW + (int64_t)h * lay.W1 + w1] = s * scale;
     }
   }
 }
@@ -200,17 +221,24 @@ __global__ __launch_bounds__(256) void alt_fwd_kernel(const T* __restrict__ f1t,
 template <typename T, int R>
 int launch_alt(const void* f1t, const void* f2t, const alt_dev_layout& d, const float* coords, int cc,
                float* out, int mode, hipStream_t st) {
-  const int gpr = (d.W1 + 15) / 16;
-  const int64_t ng = (int64_t)d.B * d.H * gpr;
-  RC_REQUIRE(ng < (1ll << 31), RC_EINVAL, "too many pixels");
+  const int bpr = (d.W1 + 63) / 64;
+  const int n_rows = d.B * d.H;
+  const int64_t nb = (int64_t)((n_rows + 7) / 8) * 8 * bpr;
+  RC_REQUIRE(nb < (1ll << 31), RC_EINVAL, "too many pixels");
   const float scale = (float)(1.0 / sqrt((double)d.D));
-  const unsigned blocks = (unsigned)((ng + 3) / 4);
-  if (mode == RC_COORD_EXACT)
-    hipLaunchKernelGGL((alt_fwd_kernel<T, R, RC_COORD_EXACT>), dim3(blocks), dim3(256), 0, st, (const T*)f1t,
-                       (const T*)f2t, d, coords, cc, out, scale, gpr, (int)ng);
-  else
-    hipLaunchKernelGGL((alt_fwd_kernel<T, R, RC_COORD_GRIDSAMPLE>), dim3(blocks), dim3(256), 0, st,
-                       (const T*)f1t, (const T*)f2t, d, coords, cc, out, scale, gpr, (int)ng);
+  const unsigned blocks = (unsigned)nb;
+#define RC_ALT(MODE, FULL)                                                                                  \
+  hipLaunchKernelGGL((alt_fwd_kernel<T, R, MODE, FULL>), dim3(blocks), dim3(256), 0, st, (const T*)f1t,    \
+                     (const T*)f2t, d, coords, cc, out, scale, bpr, n_rows)
+  const bool full = d.Dp == DMAX;
+  if (mode == RC_COORD_EXACT) {
+    if (full) RC_ALT(RC_COORD_EXACT, true);
+    else RC_ALT(RC_COORD_EXACT, false);
+  } else {
+    if (full) RC_ALT(RC_COORD_GRIDSAMPLE, true);
+    else RC_ALT(RC_COORD_GRIDSAMPLE, false);
+  }
+#undef RC_ALT
   return rc_check_launch("rc_alt_fwd");
 }
 
@@ -242,11 +270,11 @@ template <typename T>
 int run_prepare(const void* f1, const void* f2, void* f1t, void* f2t, const rc_alt_layout* a, hipStream_t st) {
   const int D = (int)a->D, Dp = (int)a->Dp, H = (int)a->H;
   const unsigned BH = (unsigned)(a->B * a->H);
-  hipLaunchKernelGGL((to_channel_last_kernel<T>), dim3((unsigned)((a->W1 + 63) / 64), (Dp + 63) / 64, BH), dim3(256),
+  hipLaunchKernelGGL((to_fragments_kernel<T>), dim3((unsigned)((a->W1 + 63) / 64), (Dp + 63) / 64, BH), dim3(256),
                      0, st, (const T*)f1, (T*)f1t, D, Dp, H, (int)a->W1, 0);
   int rc = rc_check_launch("rc_alt_prepare(f1)");
   for (int i = 0; i < a->L && !rc; ++i) {
-    hipLaunchKernelGGL((to_channel_last_kernel<T>), dim3((unsigned)((a->width[i] + 63) / 64), (Dp + 63) / 64, BH),
+    hipLaunchKernelGGL((to_fragments_kernel<T>), dim3((unsigned)((a->width[i] + 63) / 64), (Dp + 63) / 64, BH),
                        dim3(256), 0, st, (const T*)f2, (T*)f2t + a->f2_offset[i], D, Dp, H, (int)a->W2, i);
     rc = rc_check_launch("rc_alt_prepare(f2)");
   }
@@ -266,12 +294,12 @@ extern "C" int rc_alt_layout_init(int64_t B, int64_t D, int64_t H, int64_t W1, i
   memset(out, 0, sizeof(*out));
   out->B = B; out->H = H; out->W1 = W1; out->W2 = W2; out->D = D; out->L = L;
   out->Dp = (D + 31) / 32 * 32;
-  out->f1_elems = B * H * W1 * out->Dp;
+  out->f1_elems = B * H * ((W1 + 15) / 16 * 16) * out->Dp;  // positions padded to blocks of 16
   int64_t off = 0;
   for (int i = 0; i < L; ++i) {
     out->width[i] = (int32_t)(W2 >> i);
     out->f2_offset[i] = off;
-    off += B * H * (int64_t)out->width[i] * out->Dp;
+    off += B * H * (int64_t)((out->width[i] + 15) / 16 * 16) * out->Dp;
   }
   out->f2_elems = off;
   return RC_OK;
