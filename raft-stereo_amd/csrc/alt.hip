@@ -52,50 +52,75 @@ alt_dev_layout to_dev(const rc_alt_layout* a) {
   return d;
 }
 
-// NCHW [B,D,H,W] -> fragment order (see the file header) of level `level`: averages 2^level source
-// columns (pairwise tree, the order of the avg_pool2d chain, corr.py:104); zero beyond the level's
-// width (blocks are padded to 16 positions) and beyond D (padded to Dp).
+// NCHW [B,D,H,W] -> fragment order (see the file header) of levels 0..nlev-1 in one pass over the
+// source: a workgroup reads a tile of 128 positions x 64 channels, pools it 2:1 per level in LDS
+// (pairwise tree in fp32, the order of the avg_pool2d chain, corr.py:104) and writes every level's
+// blocks.  Zero beyond a level's width (blocks are padded to 16 positions) and beyond D (padded to Dp).
+struct frag_levels {
+  int nlev;
+  int width[RC_MAX_LEVELS];
+  int64_t offset[RC_MAX_LEVELS];
+};
+
 template <typename T>
 __global__ __launch_bounds__(256) void to_fragments_kernel(const T* __restrict__ src, T* __restrict__ dst,
-                                                           int D, int Dp, int H, int W, int level) {
+                                                           int D, int Dp, int H, int W, frag_levels lv) {
   constexpr int EL = 16 / (int)sizeof(T), KCH = 4 * EL;
-  __shared__ float tile[64][65];
-  const int Wl = W >> level;
-  const int nblk = (Wl + 15) >> 4, nkc = Dp / KCH;
-  const int w0 = blockIdx.x * 64, d0 = blockIdx.y * 64;
+  constexpr int KPT = 64 / KCH;      // channel chunks per tile
+  constexpr int PITCH = 128 + 64 + 32 + 16 + 1;
+  __shared__ float tile[64][PITCH];  // per channel: level 0 at [0,128), level 1 at [128,192), ...
+  const int nkc = Dp / KCH;
+  const int w0 = blockIdx.x * 128, d0 = blockIdx.y * 64;
   const int bh = blockIdx.z, b = bh / H, h = bh - b * H;
   {
-    const int wc = threadIdx.x & 63, dr = threadIdx.x >> 6;
-    const int w = w0 + wc;
-    for (int dd = dr; dd < 64; dd += 4) {
-      const int d = d0 + dd;
-      float v = 0.f;
-      if (d < D && w < Wl) {
-        const T* p = src + (((int64_t)b * D + d) * H + h) * W + ((int64_t)w << level);
-        float t[1 << (RC_MAX_LEVELS - 1)];
+    // 16 loads in flight per thread; addresses are clamped instead of predicated (a predicated load
+    // would be waited for on its own) and padding channels are zeroed afterwards
+    const int wc = threadIdx.x & 127, dr = threadIdx.x >> 7;
+    const int w = min(w0 + wc, W - 1);
+    const T* col = src + ((int64_t)b * D * H + h) * W + w;
+    const int64_t dstride = (int64_t)H * W;
 #pragma unroll
-        for (int e = 0; e < (1 << (RC_MAX_LEVELS - 1)); ++e) t[e] = (e < (1 << level)) ? rc_to_float(p[e]) : 0.f;
-        for (int n = 1 << level; n > 1; n >>= 1)
+    for (int pass = 0; pass < 2; ++pass) {
+      T v[16];
 #pragma unroll
-          for (int e = 0; e < (1 << (RC_MAX_LEVELS - 2)); ++e)
-            if (e < n / 2) t[e] = 0.5f * (t[2 * e] + t[2 * e + 1]);
-        v = t[0];
+      for (int u = 0; u < 16; ++u) v[u] = col[min(d0 + pass * 32 + 2 * u + dr, D - 1) * dstride];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int dd = pass * 32 + 2 * u + dr;
+        tile[dd][wc] = d0 + dd < D ? rc_to_float(v[u]) : 0.f;
       }
-      tile[dd][wc] = v;
     }
+  }
+  int from = 0;
+  for (int i = 1; i < lv.nlev; ++i) {
+    __syncthreads();
+    const int n = 128 >> i, to = from + (256 >> i);
+    for (int e = threadIdx.x; e < 64 * n; e += 256) {
+      const int dd = e / n, q = e - dd * n;
+      tile[dd][to + q] = 0.5f * (tile[dd][from + 2 * q] + tile[dd][from + 2 * q + 1]);
+    }
+    from = to;
   }
   __syncthreads();
   // one 16-byte fragment piece per thread and step; consecutive threads write consecutive pieces
-  constexpr int KPT = 64 / KCH;  // channel chunks per tile
-  for (int f = threadIdx.x; f < 4 * KPT * 64; f += 256) {
-    const int li = f & 15, g = (f >> 4) & 3, kcl = (f >> 6) % KPT, blk = (f >> 6) / KPT;
-    const int pb = (w0 >> 4) + blk, kc = d0 / KCH + kcl;
-    if (pb >= nblk || kc >= nkc) continue;
-    __attribute__((aligned(16))) T v[EL];
+  int col0 = 0;
+  for (int i = 0; i < lv.nlev; ++i) {
+    const int Wl = lv.width[i], nblk = (Wl + 15) >> 4;
+    const int blocks_here = 8 >> i;  // 16-position blocks of this level inside the tile
+    T* base = dst + lv.offset[i];
+    for (int f = threadIdx.x; f < blocks_here * KPT * 64; f += 256) {
+      const int li = f & 15, g = (f >> 4) & 3, kcl = (f >> 6) % KPT, blk = (f >> 6) / KPT;
+      const int pb = (w0 >> (4 + i)) + blk, kc = d0 / KCH + kcl;
+      if (pb >= nblk || kc >= nkc) continue;
+      const bool inside = pb * 16 + li < Wl;
+      __attribute__((aligned(16))) T v[EL];
 #pragma unroll
-    for (int e = 0; e < EL; ++e) v[e] = rc_from_float<T>(tile[kcl * KCH + g * EL + e][blk * 16 + li]);
-    T* q = dst + ((((int64_t)bh * nblk + pb) * nkc + kc) * 64 + g * 16 + li) * EL;
-    *reinterpret_cast<uint4*>(q) = *reinterpret_cast<const uint4*>(v);
+      for (int e = 0; e < EL; ++e)
+        v[e] = rc_from_float<T>(inside ? tile[kcl * KCH + g * EL + e][col0 + blk * 16 + li] : 0.f);
+      T* q = base + ((((int64_t)bh * nblk + pb) * nkc + kc) * 64 + g * 16 + li) * EL;
+      *reinterpret_cast<uint4*>(q) = *reinterpret_cast<const uint4*>(v);
+    }
+    col0 += 128 >> i;
   }
 }
 
@@ -270,15 +295,22 @@ template <typename T>
 int run_prepare(const void* f1, const void* f2, void* f1t, void* f2t, const rc_alt_layout* a, hipStream_t st) {
   const int D = (int)a->D, Dp = (int)a->Dp, H = (int)a->H;
   const unsigned BH = (unsigned)(a->B * a->H);
-  hipLaunchKernelGGL((to_fragments_kernel<T>), dim3((unsigned)((a->W1 + 63) / 64), (Dp + 63) / 64, BH), dim3(256),
-                     0, st, (const T*)f1, (T*)f1t, D, Dp, H, (int)a->W1, 0);
+  frag_levels one = {};
+  one.nlev = 1;
+  one.width[0] = (int)a->W1;
+  hipLaunchKernelGGL((to_fragments_kernel<T>), dim3((unsigned)((a->W1 + 127) / 128), (Dp + 63) / 64, BH), dim3(256),
+                     0, st, (const T*)f1, (T*)f1t, D, Dp, H, (int)a->W1, one);
   int rc = rc_check_launch("rc_alt_prepare(f1)");
-  for (int i = 0; i < a->L && !rc; ++i) {
-    hipLaunchKernelGGL((to_fragments_kernel<T>), dim3((unsigned)((a->width[i] + 63) / 64), (Dp + 63) / 64, BH),
-                       dim3(256), 0, st, (const T*)f2, (T*)f2t + a->f2_offset[i], D, Dp, H, (int)a->W2, i);
-    rc = rc_check_launch("rc_alt_prepare(f2)");
+  if (rc) return rc;
+  frag_levels all = {};
+  all.nlev = a->L;
+  for (int i = 0; i < a->L; ++i) {
+    all.width[i] = a->width[i];
+    all.offset[i] = a->f2_offset[i];
   }
-  return rc;
+  hipLaunchKernelGGL((to_fragments_kernel<T>), dim3((unsigned)((a->W2 + 127) / 128), (Dp + 63) / 64, BH), dim3(256),
+                     0, st, (const T*)f2, (T*)f2t, D, Dp, H, (int)a->W2, all);
+  return rc_check_launch("rc_alt_prepare(f2)");
 }
 
 }  // namespace
