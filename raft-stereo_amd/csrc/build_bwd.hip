@@ -1,15 +1,16 @@
-// Adjoint of the pyramid build: grad pyramid (float, skewed) -> d fmap1, d fmap2.
+// Adjoint of the pyramid build: gradient of the volume -> d fmap1, d fmap2.
 //
 // Autograd of core/corr.py:119-125 (avg_pool2d chain) and :154-156 (einsum, / sqrt(D)).
-// Two steps on one stream:
-//   1. unskew_fold: reads every 16-byte block once (coalesced), folds levels 1..L-1 into level 0
-//      (each pooled cell spreads 2^-i of its gradient over its 2^i children), scales by
-//      1/sqrt(D), and writes the dense dC[b,h,w1,w2] in the compute type, rows zero padded to a
-//      multiple of 32.
-//   2. two MFMA contractions per image row, feature rows straight from global memory, the dC slab
-//      staged through LDS:
+//   rc_build_bwd_dense takes the dense gradient of level 0, dC[b,h,w1,w2] in the feature type
+//   (rows zero padded to a multiple of 32; rc_lookup_bwd_dense in lookup.hip writes it with the
+//   levels already folded and 1/sqrt(D) applied), and runs two MFMA contractions per image row,
+//   both operands staged through LDS with coalesced loads:
 //        df1[b,:,h,:] = f2[b,:,h,:] (D x W2)  *  dC[b,h]^T (W2 x W1)     (plain LDS image)
 //        df2[b,:,h,:] = f1[b,:,h,:] (D x W1)  *  dC[b,h]   (W1 x W2)     (transposing LDS reads)
+//   rc_build_bwd takes the float gradient pyramid (group-skewed layout) that rc_lookup_bwd
+//   accumulates: unskew_fold reads every 16-byte block once, folds levels 1..L-1 into level 0
+//   (a pooled cell spreads 2^-i of its gradient over its 2^i children), scales by 1/sqrt(D) and
+//   writes that dense dC into the caller's workspace; then the same two contractions.
 #include "rc_common.h"
 
 #include <math.h>
