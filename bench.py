@@ -140,6 +140,38 @@ class Step:
         self.events = []
 
 
+def fused_convc1(step, cfg, device, n=50):
+    """SURVEY 8(f) rank 1, measured beside the contract's metric: relu(convc1(lookup)) in one kernel
+    (rc_lookup_convc1_fwd) against the library's lookup followed by torch's 1x1 convolution + ReLU in
+    the pyramid's dtype (what autocast runs for core/update.py:78).  HIP events on the current stream."""
+    g = torch.Generator(device=device).manual_seed(77)
+    dt = step.f1.dtype
+    wgt = torch.randn((64, LEVELS * (2 * RADIUS + 1), 1, 1), generator=g, device=device) * 0.2
+    bias = torch.randn((64,), generator=g, device=device)
+    wq, bq = wgt.to(dt), bias.to(dt)
+    with torch.no_grad():
+        blk = step.cls(step.f1, step.f2, num_levels=LEVELS, radius=RADIUS)
+
+        def timed(fn):
+            for _ in range(5):
+                fn()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(n):
+                fn()
+            b.record()
+            b.synchronize()
+            return a.elapsed_time(b) / n * 1e3
+
+        fused = timed(lambda: blk.lookup_convc1(step.coords, wgt, bias))
+        unfused = timed(lambda: torch.relu_(torch.nn.functional.conv2d(blk(step.coords).to(dt), wq, bq)))
+    px = cfg["batch"] * cfg["H"] * cfg["W"]
+    s = 4 if cfg["dtype"] == "f32" else 2
+    alg = px * (LEVELS * (2 * RADIUS + 2) * s + 4 + 64 * s)
+    return dict(fused_lookup_convc1_us=round(fused, 2), unfused_lookup_then_convc1_us=round(unfused, 2),
+                fused_lookup_convc1_gbps=round(alg / (fused * 1e-6) / 1e9, 1))
+
+
 def cpu_baseline(cfg, budget_s=15.0):
     """The reference's reg path (torch ops port, oracle/reg_torch.py) on this host's cores, on a
     bounded sample of the same workload: ONE pair of this shape in fp32, repeated for ~budget_s."""
@@ -253,6 +285,9 @@ def main():
         extra.update(prepare_ms=round(build_ms, 4))
     if cfg["train"]:
         extra.update(backward_ms=round(float(np.median(step.bwd_ms)), 4))
+
+    if not is_alt and not cfg["train"] and rank == 0:
+        extra.update(fused_convc1(step, cfg, device))      # after the timed region: not part of `value`
 
     roof["traffic"] = measured_traffic(args.workload, cfg["batch"], roof["kernel"])
     line = {

@@ -42,6 +42,8 @@ extern "C" {
 #define RC_MAX_LEVELS 4
 #define RC_MAX_RADIUS 8
 #define RC_MAX_FUSED_LOOKUPS 32  /* lookups one rc_lookup_bwd_dense call can take */
+#define RC_CONVC1_OUT 64         /* output channels of the motion encoder's convc1 (core/update.py:71) */
+#define RC_CONVC1_MAX_RADIUS 7   /* rc_lookup_convc1_fwd: a level's 2r+1 taps must fit 16 MFMA K slots */
 
 /* element types of feature maps / volumes */
 enum { RC_F32 = 0, RC_F16 = 1, RC_BF16 = 2 };
@@ -148,8 +150,8 @@ int rc_build_bwd(const float* grad_vol, const rc_layout* glay, const void* f1, c
  * (autograd of corr.py:127-146 / sampler_kernel.cu:63-105 called once per GRU iteration) plus the
  * pyramid fold of rc_build_bwd, without ever touching a gradient pyramid.  rc_build_bwd_dense
  * then contracts it with the feature maps (autograd of corr.py:154-156); df1/df2 and dense_grad
- * have the feature dtype.  Sums over lookups are formed with LDS float atomics: the order, and
- * so the last bit, can differ between runs.
+ * have the feature dtype.  A thread owns the per-level gradient row of its pixel (in LDS, f32) and
+ * adds the lookups in list order: no atomics, results are reproducible run to run.
  */
 int64_t rc_dense_grad_ld(const rc_layout* glay);
 int rc_lookup_bwd_dense(const float* const* coords_list, const float* const* grad_out_list,
@@ -157,6 +159,23 @@ int rc_lookup_bwd_dense(const float* const* coords_list, const float* const* gra
                         int64_t D, int out_dtype, int radius, int coord_mode, void* stream);
 int rc_build_bwd_dense(const void* dense_grad, const rc_layout* glay, const void* f1, const void* f2,
                        void* df1, void* df2, int64_t D, int in_dtype, void* stream);
+
+/*
+ * SURVEY.md section 8(f) rank 1 -- lookup fused with the first layer of the motion encoder:
+ *     out = relu(convc1(lookup(coords))),  convc1 = nn.Conv2d(L*(2r+1), 64, 1)  (core/update.py:71,78
+ * applied to the result of core/raft_stereo.py:110).  The L*(2r+1)-channel tensor is never written.
+ * rc_convc1_pack arranges the convolution weight -- float [64, L*(2r+1)] as nn.Conv2d stores it,
+ * input channel = level*(2r+1) + tap -- into MFMA fragment order for a pyramid of `dtype`:
+ * `packed` holds RC_CONVC1_OUT*64 elements of that type (call again whenever the weight changes).
+ * rc_lookup_convc1_fwd: vol/lay/coords as in rc_lookup_fwd; bias float [64]; out [B,64,H,W1] in the
+ * pyramid's dtype (RC_F16/RC_BF16: taps rounded to that type, f32 accumulation -- what autocast makes
+ * of the convolution; RC_F32: f32 throughout); relu != 0 applies the activation.  radius <= 7.
+ */
+int rc_convc1_pack(const float* weight, int num_levels, int radius, int dtype, void* packed,
+                   void* stream);
+int rc_lookup_convc1_fwd(const void* vol, const rc_layout* lay, const float* coords,
+                         int coords_channels, const void* packed_weight, const float* bias,
+                         void* out, int radius, int coord_mode, int relu, void* stream);
 
 /*
  * Drop-in for the reference's `corr_sampler` extension (sampler/sampler.cpp:48-51): one

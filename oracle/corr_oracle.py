@@ -224,6 +224,22 @@ def alt_lookup(f1, f2, coords, num_levels, radius, mode=EXACT):
     return np.ascontiguousarray(out.transpose(0, 3, 1, 2))
 
 
+def convc1_relu(corr, weight, bias, relu=True, round_to=None):
+    """First layer of the motion encoder on a lookup result (core/update.py:71,78):
+    `F.relu(convc1(corr))`, convc1 = nn.Conv2d(L*(2r+1), 64, 1).  corr [B,K,H,W],
+    weight [64,K] (or [64,K,1,1]), bias [64] -> [B,64,H,W].  `round_to` (a function) rounds corr
+    and the weight to the 16-bit type first, as autocast does before the convolution."""
+    corr = np.asarray(corr, dtype=F32)
+    w = np.asarray(weight, dtype=F32).reshape(np.asarray(weight).shape[0], -1)
+    if round_to is not None:
+        corr, w = round_to(corr), round_to(w)
+    out = np.einsum("ok,bkhw->bohw", w.astype(np.float64), corr.astype(np.float64))
+    out = out + np.asarray(bias, dtype=np.float64)[None, :, None, None]
+    if relu:
+        out = np.maximum(out, 0.0)
+    return out.astype(F32)
+
+
 # ----------------------------------------------------------------------------- helpers
 def rel_to_max(a, b):
     """The parity metric of SURVEY.md 8(d): max|a-b| / max|b|."""

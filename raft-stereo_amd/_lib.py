@@ -9,6 +9,8 @@ import os
 RC_MAX_LEVELS = 4
 RC_MAX_RADIUS = 8
 RC_MAX_FUSED_LOOKUPS = 32
+RC_CONVC1_OUT = 64
+RC_CONVC1_MAX_RADIUS = 7
 RC_F32, RC_F16, RC_BF16 = 0, 1, 2
 RC_COORD_EXACT, RC_COORD_GRIDSAMPLE = 0, 1
 RC_WRAP_ROWS = 32
@@ -55,6 +57,8 @@ SIGNATURES = {
     "rc_dense_grad_ld": (_L, [_LP]),
     "rc_lookup_bwd_dense": (_I, [C.POINTER(_P), C.POINTER(_P), _I, _I, _P, _LP, _L, _I, _I, _I, _P]),
     "rc_build_bwd_dense": (_I, [_P, _LP, _P, _P, _P, _P, _L, _I, _P]),
+    "rc_convc1_pack": (_I, [_P, _I, _I, _I, _P, _P]),
+    "rc_lookup_convc1_fwd": (_I, [_P, _LP, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "rc_sampler_fwd": (_I, [_P, _P, _I, _P, _L, _L, _L, _L, _I, _I, _P]),
     "rc_sampler_bwd": (_I, [_P, _I, _P, _P, _L, _L, _L, _L, _I, _I, _P]),
     "rc_alt_layout_init": (_I, [_L, _L, _L, _L, _L, _I, _ALP]),

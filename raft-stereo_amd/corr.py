@@ -225,6 +225,44 @@ class CorrBlock1DHip:
             return _LookupFn.apply(self._token, coords, self)
         return self._lookup(coords)
 
+    def lookup_convc1(self, coords, weight, bias, relu=True):
+        """`F.relu(convc1(block(coords)))` (core/update.py:71,78 on the result of
+        core/raft_stereo.py:110) in one kernel: the L*(2r+1)-channel tensor is never written.
+
+        weight: convc1.weight `[64, L*(2r+1), 1, 1]` (or `[64, L*(2r+1)]`), bias `[64]`.  Returns
+        `[B, 64, H, W]` in the pyramid's dtype: fp16/bf16 under mixed precision (what autocast makes
+        of the convolution), fp32 otherwise.  Inference only (SURVEY.md section 8 f, rank 1)."""
+        if torch.is_grad_enabled() and (self._token is not None or weight.requires_grad or bias.requires_grad):
+            raise RuntimeError("lookup_convc1 is forward-only: call it under torch.no_grad()")
+        K = self.num_levels * (2 * self.radius + 1)
+        if weight.numel() != _lib.RC_CONVC1_OUT * K or weight.shape[0] != _lib.RC_CONVC1_OUT \
+                or bias.numel() != _lib.RC_CONVC1_OUT:
+            raise ValueError(f"convc1 weight must be [{_lib.RC_CONVC1_OUT}, {K}(,1,1)] and bias "
+                             f"[{_lib.RC_CONVC1_OUT}], got {tuple(weight.shape)} and {tuple(bias.shape)}")
+        if self.radius > _lib.RC_CONVC1_MAX_RADIUS:
+            raise ValueError(f"lookup_convc1 supports radius <= {_lib.RC_CONVC1_MAX_RADIUS}")
+        if weight.device != self.device or bias.device != self.device:
+            raise RuntimeError("convc1 parameters live on a different device than the feature maps")
+        coords = _check_coords(coords, self.B, self.H, self.W1, self.device)
+        key = (weight.data_ptr(), weight._version, bias.data_ptr(), bias._version)
+        with torch.cuda.device(self.device):
+            st = _stream(self.device)
+            if getattr(self, "_convc1_key", None) != key:
+                w32 = weight.detach().reshape(_lib.RC_CONVC1_OUT, K).float().contiguous()
+                self._convc1_packed = torch.empty(_lib.RC_CONVC1_OUT * 64, dtype=self.volume_torch_dtype,
+                                                  device=self.device)
+                check(lib.rc_convc1_pack(w32.data_ptr(), self.num_levels, self.radius, self.vol_dtype,
+                                         self._convc1_packed.data_ptr(), st), "rc_convc1_pack")
+                self._convc1_bias = bias.detach().float().contiguous().clone()
+                self._convc1_key = key
+            out = torch.empty((self.B, _lib.RC_CONVC1_OUT, self.H, self.W1), dtype=self.volume_torch_dtype,
+                              device=self.device)
+            check(lib.rc_lookup_convc1_fwd(self._vol_ptr, self._lay_ref, coords.data_ptr(), coords.shape[1],
+                                           self._convc1_packed.data_ptr(), self._convc1_bias.data_ptr(),
+                                           out.data_ptr(), self.radius, self.coord_mode, int(bool(relu)), st),
+                  "rc_lookup_convc1_fwd")
+        return out
+
     # -- test / debug helper: the pyramid in the reference's dense layout
     def dense_level(self, i, volume=None, layout=None):
         """Level i as a dense [B,H,W1,W2>>i] tensor (un-skews the private layout with torch

@@ -1,0 +1,356 @@
+// Correlation lookup fused with the motion encoder's first layer:
+//     out = relu(convc1(lookup(coords)))        convc1 = 1x1 convolution, L*(2r+1) -> 64 channels
+//
+// Replaces core/corr.py:127-146 / :44-51 (the lookup) followed by core/update.py:71,78
+// (`cor = F.relu(self.convc1(corr))`) of the reference: the L*(2r+1)-channel fp32 tensor between
+// the two (144 B written + 144 B read back per pixel and iteration) never exists.
+//
+// A wave owns 64 consecutive pixels of one image row and handles them 16 at a time.  In a pass,
+// lane (g, li) = (lane / 16, lane % 16) produces the 2r+1 taps of pixel li at pyramid LEVEL g,
+// with the same 16-byte block loads and in-register window decode as the plain lookup.  That is
+// exactly the B-operand layout of the MFMA (column = pixel, K slot = 16 g + tap), so the taps go
+// straight from the interpolation into  C[out channel][pixel] += Wp[out channel][K] * taps[K][pixel],
+// K = 4 levels x 16 tap slots (unused slots carry zero weights).  Weights come pre-arranged in
+// fragment order (rc_convc1_pack); the accumulators start from the bias.  After the four passes a
+// 4x4 transpose over the lane rows (v_permlane16/32_swap) leaves lane = pixel, so every output
+// channel plane is written in one contiguous run per wave.
+//   16-bit pyramid: taps rounded to the pyramid's type, v_mfma_f32_16x16x32 (f32 accumulate),
+//                   output in that type (what autocast makes of convc1);
+//   f32 pyramid:    v_mfma_f32_16x16x4_f32, f32 output.
+#include "rc_common.h"
+#include "window.h"
+
+#include <math.h>
+
+namespace {
+
+typedef short s8v __attribute__((ext_vector_type(8)));
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+typedef __bf16 b8v __attribute__((ext_vector_type(8)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+
+constexpr int FC_OUT = RC_CONVC1_OUT;  // output channels of convc1 (core/update.py:71)
+constexpr int FC_SLOTS = 16;           // tap slots per level in the packed weights
+constexpr int FC_THREADS = 256;
+
+template <typename T> __device__ __forceinline__ f4v mfma16(uint4 a, uint4 b, f4v c);
+template <> __device__ __forceinline__ f4v mfma16<rc_half>(uint4 a, uint4 b, f4v c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8v, a), __builtin_bit_cast(h8v, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f4v mfma16<rc_bf16>(uint4 a, uint4 b, f4v c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8v, a), __builtin_bit_cast(b8v, b), c, 0, 0, 0);
+}
+
+template <typename VT> __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+  typedef VT v2 __attribute__((ext_vector_type(2)));
+  const f2v f = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, v2));
+}
+
+__device__ __forceinline__ void swap16(float& x, float& y) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  x = __uint_as_float(r[0]);
+  y = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void swap32(float& x, float& y) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  x = __uint_as_float(r[0]);
+  y = __uint_as_float(r[1]);
+}
+
+template <typename A> __device__ __forceinline__ A pick4(const A (&a)[RC_MAX_LEVELS], int i) {
+  return i == 0 ? a[0] : (i == 1 ? a[1] : (i == 2 ? a[2] : a[3]));
+}
+
+// Packed weights (FC_OUT * 64 elements of the pyramid's type), t = out / 16, lane = 16 g + li,
+// out = 16 t + li, tap slot of level g:
+//   16-bit: [(t*2 + half)*64 + lane]*8 + e   <- W[out][g*NT + 8*half + e]
+//   f32:    [(t*16 + e)*64 + lane]           <- W[out][g*NT + e]
+// zero where the level or the tap does not exist.
+template <typename T>
+__global__ __launch_bounds__(256) void convc1_pack_kernel(const float* __restrict__ w, T* __restrict__ packed, int L,
+                                                          int NT) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= FC_OUT * 64) return;
+  int t, lane, tap;
+  if (sizeof(T) == 2) {
+    const int e = idx & 7, half = (idx >> 9) & 1;
+    lane = (idx >> 3) & 63;
+    t = idx >> 10;
+    tap = 8 * half + e;
+  } else {
+    lane = idx & 63;
+    tap = (idx >> 6) & 15;
+    t = idx >> 10;
+  }
+  const int li = lane & 15, g = lane >> 4;
+  const float v = (g < L && tap < NT) ? w[(16 * t + li) * (L * NT) + g * NT + tap] : 0.f;
+  packed[idx] = rc_from_float<T>(v);
+}
+
+template <typename VT, int R, int MODE>
+__global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __restrict__ vol, rc_dev_layout lay,
+                                                                   const float* __restrict__ coords,
+                                                                   int coords_channels,
+                                                                   const VT* __restrict__ wpack,
+                                                                   const float* __restrict__ bias,
+                                                                   VT* __restrict__ out, int chunks_per_row,
+                                                                   int n_items, int relu) {
+  constexpr bool IS16 = sizeof(VT) == 2;
+  constexpr int RB = vt_info<VT>::RB, LG = vt_info<VT>::LG;
+  using WI = win_info<RB, R, MODE>;
+  constexpr int NT = WI::NT, EXT = WI::EXT, NW = WI::NW, NBLK = WI::NBLK, ND = WI::ND;
+  static_assert(NT <= FC_SLOTS, "a level's taps must fit its slots");
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int item = blockIdx.x * (FC_THREADS / 64) + wave;  // (row, 64-pixel chunk), wave-uniform
+  if (item >= n_items) return;
+  const int bh = item / chunks_per_row;
+  const int c0 = (item - bh * chunks_per_row) * 64;
+  const int b = bh / lay.H, h = bh - b * lay.H;
+  const int64_t HW = (int64_t)lay.H * lay.W1;
+  const int g = lane >> 4, li = lane & 15;
+  const uint32_t blk_bytes = (uint32_t)lay.pitch * 16u;
+
+  // the lane's level
+  const bool has_level = g < lay.L;
+  const int i = has_level ? g : 0;
+  const int Wi = pick4(lay.width, i), nb = pick4(lay.widthp, i) >> LG, rbias = pick4(lay.bias, i);
+  const float inv = 1.0f / (float)(1 << i);
+  const char* lvl = reinterpret_cast<const char*>(vol) + pick4(lay.offset, i) * (int64_t)sizeof(VT) +
+                    (int64_t)bh * nb * blk_bytes;
+  const bool tiny = nb < NBLK;
+
+  // weights (A operand: row = out channel 16 t + li, K slots of level g) and bias (C rows 4 g + r)
+  uint4 wa16[4][2];
+  float wa32[4][NT];
+  f4v acc[4][4];  // [pass][t]
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if constexpr (IS16) {
+      wa16[t][0] = reinterpret_cast<const uint4*>(wpack)[(t * 2 + 0) * 64 + lane];
+      wa16[t][1] = reinterpret_cast<const uint4*>(wpack)[(t * 2 + 1) * 64 + lane];
+    } else {
+#pragma unroll
+      for (int e = 0; e < NT; ++e) wa32[t][e] = reinterpret_cast<const float*>(wpack)[(t * 16 + e) * 64 + lane];
+    }
+    const f4v bv = *reinterpret_cast<const f4v*>(bias + 16 * t + 4 * g);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc[s][t] = bv;
+  }
+
+  // ---- phase 1: window addresses and block loads of the four passes
+  uint32_t d[4][ND];
+  win_pos pos[4];
+  float xi_[4], frac[4];
+  const float* crow = coords + uniform(((int64_t)b * coords_channels) * HW + (int64_t)h * lay.W1);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int w1 = min(c0 + 16 * s + li, lay.W1 - 1);
+    const float xi = crow[w1] * inv;
+    const float xf = floorf(xi);
+    xi_[s] = xi;
+    frac[s] = xi - xf;
+    pos[s] = locate_window<RB, LG, NW>(rc_safe_int(xf) - R - EXT, w1, i, Wi, nb, rbias);
+#pragma unroll
+    for (int k = 0; k < NBLK; ++k) {
+      const uint32_t sb = row_step(pos[s].sb0, (uint32_t)min(k, pos[s].nbk), (uint32_t)nb, tiny);
+      const uint4 q = *reinterpret_cast<const uint4*>(lvl + (__umul24(sb, blk_bytes) + (uint32_t)w1 * 16u));
+      d[s][4 * k + 0] = q.x;
+      d[s][4 * k + 1] = q.y;
+      d[s][4 * k + 2] = q.z;
+      d[s][4 * k + 3] = q.w;
+    }
+  }
+
+  // ---- phase 2: taps of (pixel, level), then the 1x1 convolution on the matrix cores
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const bool live = has_level && (c0 + 16 * s + li < lay.W1);
+    float v[NW];
+    decode_window<VT, NW, ND>(d[s], pos[s].o, v);
+    if (__any(pos[s].edge)) {  // interior waves skip the zero padding
+#pragma unroll
+      for (int m = 0; m < NW; ++m) v[m] = ((unsigned)(pos[s].wbase + m) < (unsigned)Wi) ? v[m] : 0.f;
+    }
+    const float keep = live ? 1.0f : 0.f;  // lanes without a level or past the row end contribute zero taps
+
+    float tap[FC_SLOTS];
+#pragma unroll
+    for (int k = NT; k < FC_SLOTS; ++k) tap[k] = 0.f;
+    if constexpr (MODE == RC_COORD_EXACT) {
+      const float a = frac[s] * keep, bw = keep - a;
+#pragma unroll
+      for (int k = 0; k < NT; ++k) tap[k] = v[k] * bw + v[k + 1] * a;
+    } else {
+      const float wm1 = (float)(Wi - 1);
+#pragma unroll
+      for (int k = 0; k < NT; ++k) {
+        int i0k;
+        float w0, w1w;
+        rc_gridsample_coords(xi_[s], k - R, wm1, &i0k, &w0, &w1w);
+        const int dlt = i0k - (pos[s].wbase + EXT + k);  // -1, 0 or +1
+        const float va = dlt < 0 ? v[k] : (dlt > 0 ? v[k + 2] : v[k + 1]);
+        const float vb = dlt < 0 ? v[k + 1] : (dlt > 0 ? v[k + 3] : v[k + 2]);
+        tap[k] = (va * w0 + vb * w1w) * keep;
+      }
+    }
+
+    if constexpr (IS16) {
+      const uint4 b0 = make_uint4(pack2<VT>(tap[0], tap[1]), pack2<VT>(tap[2], tap[3]), pack2<VT>(tap[4], tap[5]),
+                                  pack2<VT>(tap[6], tap[7]));
+      const uint4 b1 = make_uint4(pack2<VT>(tap[8], tap[9]), pack2<VT>(tap[10], tap[11]),
+                                  pack2<VT>(tap[12], tap[13]), pack2<VT>(tap[14], tap[15]));
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        acc[s][t] = mfma16<VT>(wa16[t][0], b0, acc[s][t]);
+        if (NT > 8) acc[s][t] = mfma16<VT>(wa16[t][1], b1, acc[s][t]);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < NT; ++e)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa32[t][e], tap[e], acc[s][t], 0, 0, 0);
+    }
+  }
+
+  // ---- phase 3: lane rows <-> passes, so that lane = pixel; activation; one run per channel plane
+  const int w1 = c0 + lane;
+  VT* orow = out + uniform(((int64_t)b * FC_OUT) * HW + (int64_t)h * lay.W1 + c0);
+  // 16-bit outputs leave as dwords when rows start on even pixels: neighbouring lanes trade one
+  // channel each (even lanes keep the first channel of a pair for pixels (l, l+1), odd lanes the
+  // second for (l-1, l)), so one store instruction writes two 128-byte runs
+  const bool pairs = IS16 && (lay.W1 & 1) == 0 && (reinterpret_cast<uintptr_t>(out) & 3) == 0;
+  const bool odd = lane & 1;
+  const int64_t plane_b = HW * (int64_t)sizeof(VT);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float x0 = acc[0][t][r], x1 = acc[1][t][r], x2 = acc[2][t][r], x3 = acc[3][t][r];
+      swap16(x0, x1);
+      swap16(x2, x3);
+      swap32(x0, x2);
+      swap32(x1, x3);
+      float xs[4] = {x0, x1, x2, x3};  // channel 16 t + 4 s + r of pixel c0 + lane
+#pragma unroll
+      for (int s = 0; s < 4; ++s) xs[s] = relu ? fmaxf(xs[s], 0.f) : xs[s];
+      bool stored = false;
+      if constexpr (IS16) {
+        if (pairs) {  // wave-uniform
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            const float a = xs[2 * p], bb = xs[2 * p + 1];  // channels ca, ca + 4
+            const int ca = 16 * t + 8 * p + r;
+            const float recv = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(odd ? a : bb),
+                                                                       0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true));
+            const uint32_t word = pack2<VT>(odd ? recv : a, odd ? bb : recv);
+            char* dst = reinterpret_cast<char*>(orow) + uniform((int64_t)ca * plane_b);
+            const uint32_t voff =
+                (odd ? (uint32_t)(4 * plane_b) : 0u) + (uint32_t)(lane & ~1) * (uint32_t)sizeof(VT);
+            if ((w1 & ~1) < lay.W1) *reinterpret_cast<uint32_t*>(dst + voff) = word;
+          }
+          stored = true;
+        }
+      }
+      if (!stored) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          if (w1 < lay.W1) (orow + uniform((int64_t)(16 * t + 4 * s + r) * HW))[lane] = rc_from_float<VT>(xs[s]);
+      }
+    }
+  }
+}
+
+template <typename VT, int R>
+int launch_fused(const void* vol, rc_dev_layout d, const float* coords, int cc, const void* wpack,
+                 const float* bias, void* out, int mode, int relu, hipStream_t st) {
+  const int chunks = (d.W1 + 63) / 64;
+  const int n_items = (int)((int64_t)d.B * d.H * chunks);
+  const int blocks = (n_items + (FC_THREADS / 64) - 1) / (FC_THREADS / 64);
+  if (mode == RC_COORD_EXACT) {
+    set_row_bias(d, vt_info<VT>::RB, win_info<vt_info<VT>::RB, R, RC_COORD_EXACT>::NW);
+    hipLaunchKernelGGL((lookup_convc1_kernel<VT, R, RC_COORD_EXACT>), dim3(blocks), dim3(FC_THREADS), 0, st,
+                       (const VT*)vol, d, coords, cc, (const VT*)wpack, bias, (VT*)out, chunks, n_items, relu);
+  } else {
+    set_row_bias(d, vt_info<VT>::RB, win_info<vt_info<VT>::RB, R, RC_COORD_GRIDSAMPLE>::NW);
+    hipLaunchKernelGGL((lookup_convc1_kernel<VT, R, RC_COORD_GRIDSAMPLE>), dim3(blocks), dim3(FC_THREADS), 0, st,
+                       (const VT*)vol, d, coords, cc, (const VT*)wpack, bias, (VT*)out, chunks, n_items, relu);
+  }
+  return rc_check_launch("rc_lookup_convc1_fwd");
+}
+
+template <typename VT>
+int dispatch_fused(const void* vol, const rc_dev_layout& d, const float* coords, int cc, const void* wpack,
+                   const float* bias, void* out, int radius, int mode, int relu, hipStream_t st) {
+  switch (radius) {
+    case 1: return launch_fused<VT, 1>(vol, d, coords, cc, wpack, bias, out, mode, relu, st);
+    case 2: return launch_fused<VT, 2>(vol, d, coords, cc, wpack, bias, out, mode, relu, st);
+    case 3: return launch_fused<VT, 3>(vol, d, coords, cc, wpack, bias, out, mode, relu, st);
+    case 4: return launch_fused<VT, 4>(vol, d, coords, cc, wpack, bias, out, mode, relu, st);
+    case 5: return launch_fused<VT, 5>(vol, d, coords, cc, wpack, bias, out, mode, relu, st);
+    case 6: return launch_fused<VT, 6>(vol, d, coords, cc, wpack, bias, out, mode, relu, st);
+    case 7: return launch_fused<VT, 7>(vol, d, coords, cc, wpack, bias, out, mode, relu, st);
+  }
+  rc_set_error("fused lookup + convc1: radius %d outside 1..%d", radius, RC_CONVC1_MAX_RADIUS);
+  return RC_EUNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" int rc_convc1_pack(const float* weight, int num_levels, int radius, int dtype, void* packed,
+                              void* stream) {
+  RC_REQUIRE(weight && packed, RC_EINVAL, "null pointer argument");
+  RC_REQUIRE(num_levels >= 1 && num_levels <= RC_MAX_LEVELS, RC_EUNSUPPORTED, "num_levels %d outside 1..%d",
+             num_levels, RC_MAX_LEVELS);
+  RC_REQUIRE(radius >= 1 && radius <= RC_CONVC1_MAX_RADIUS, RC_EUNSUPPORTED,
+             "fused lookup + convc1: radius %d outside 1..%d", radius, RC_CONVC1_MAX_RADIUS);
+  RC_REQUIRE((uintptr_t)packed % 16 == 0, RC_EINVAL, "packed weights must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int NT = 2 * radius + 1, blocks = FC_OUT * 64 / 256;
+  switch (dtype) {
+    case RC_F32:
+      hipLaunchKernelGGL((convc1_pack_kernel<float>), dim3(blocks), dim3(256), 0, st, weight, (float*)packed,
+                         num_levels, NT);
+      break;
+    case RC_F16:
+      hipLaunchKernelGGL((convc1_pack_kernel<rc_half>), dim3(blocks), dim3(256), 0, st, weight, (rc_half*)packed,
+                         num_levels, NT);
+      break;
+    case RC_BF16:
+      hipLaunchKernelGGL((convc1_pack_kernel<rc_bf16>), dim3(blocks), dim3(256), 0, st, weight, (rc_bf16*)packed,
+                         num_levels, NT);
+      break;
+    default: rc_set_error("unknown dtype %d", dtype); return RC_EUNSUPPORTED;
+  }
+  return rc_check_launch("rc_convc1_pack");
+}
+
+extern "C" int rc_lookup_convc1_fwd(const void* vol, const rc_layout* lay, const float* coords,
+                                    int coords_channels, const void* packed_weight, const float* bias, void* out,
+                                    int radius, int coord_mode, int relu, void* stream) {
+  RC_REQUIRE(packed_weight && bias, RC_EINVAL, "null pointer argument");
+  RC_REQUIRE(radius <= RC_CONVC1_MAX_RADIUS, RC_EUNSUPPORTED, "fused lookup + convc1: radius %d outside 1..%d",
+             radius, RC_CONVC1_MAX_RADIUS);
+  int rc = check_common(lay, vol, coords, out, coords_channels, radius, coord_mode);
+  if (rc) return rc;
+  RC_REQUIRE((uintptr_t)packed_weight % 16 == 0 && (uintptr_t)bias % 16 == 0, RC_EINVAL,
+             "packed weights and bias must be 16-byte aligned");
+  const rc_dev_layout d = rc_to_dev(lay);
+  hipStream_t st = (hipStream_t)stream;
+  switch (lay->dtype) {
+    case RC_F32:
+      return dispatch_fused<float>(vol, d, coords, coords_channels, packed_weight, bias, out, radius, coord_mode,
+                                   relu, st);
+    case RC_F16:
+      return dispatch_fused<rc_half>(vol, d, coords, coords_channels, packed_weight, bias, out, radius, coord_mode,
+                                     relu, st);
+    case RC_BF16:
+      return dispatch_fused<rc_bf16>(vol, d, coords, coords_channels, packed_weight, bias, out, radius, coord_mode,
+                                     relu, st);
+  }
+  rc_set_error("unknown pyramid dtype %d", lay->dtype);
+  return RC_EUNSUPPORTED;
+}

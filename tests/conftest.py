@@ -8,7 +8,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
-GOLDEN_CASES = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz"))
+_NPZ = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz"))
+GOLDEN_CASES = [n for n in _NPZ if not n.startswith("convc1_")]
+# cases that also have the reference's relu(convc1(lookup)) activations (make_golden_convc1.py)
+CONVC1_CASES = [n[len("convc1_"):] for n in _NPZ if n.startswith("convc1_")]
 
 
 def pytest_configure(config):

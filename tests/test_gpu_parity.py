@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from oracle import corr_oracle as O
-from conftest import GOLDEN_CASES
+from conftest import CONVC1_CASES, GOLDEN_CASES
 
 pytestmark = pytest.mark.gpu
 
@@ -333,6 +333,75 @@ def test_alt_more_lookups_than_one_fused_call(R):
     blk = R.CorrBlock1DHip(f1, f2)
     (blk(c) * G).sum().backward()
     assert rel(many1, (70 * f1.grad).cpu().numpy()) < 1e-5 and rel(many2, (70 * f2.grad).cpu().numpy()) < 1e-5
+
+
+# ------------------------------------------------------------------ fused lookup + convc1
+@pytest.mark.parametrize("case", CONVC1_CASES)
+@pytest.mark.parametrize("kind", KINDS)
+def test_lookup_convc1_fp32_matches_reference_motion_encoder(R, golden, case, kind):
+    g, c = golden(case), golden("convc1_" + case)
+    L, r = int(g["L"]), int(g["r"])
+    with torch.no_grad():
+        blk = R.CorrBlock1DHip(dev(g["f1"]), dev(g["f2"]), num_levels=L, radius=r)
+        act = blk.lookup_convc1(dev(g[f"coords_{kind}"]), dev(c["weight"]), dev(c["bias"]))
+        pre = blk.lookup_convc1(dev(g[f"coords_{kind}"]), dev(c["weight"]), dev(c["bias"]), relu=False)
+    assert act.dtype == torch.float32 and tuple(act.shape) == c[f"act_{kind}"].shape
+    assert rel(act, c[f"act_{kind}"]) < TOL32
+    assert rel(pre, O.convc1_relu(g[f"lookup_{kind}"], c["weight"], c["bias"], relu=False)) < TOL32
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("case", CONVC1_CASES)
+def test_lookup_convc1_16bit(R, golden, case, dtype):
+    """16-bit pyramid: the taps and the weight are rounded to the pyramid's type before the
+    convolution (autocast), accumulation in fp32; compared with the oracle on the rounded inputs."""
+    g, c = golden(case), golden("convc1_" + case)
+    L, r = int(g["L"]), int(g["r"])
+    rnd = (lambda a: a.astype(np.float16).astype(np.float32)) if dtype == torch.float16 else O.round_bf16
+    f1, f2 = rnd(g["f1"]), rnd(g["f2"])
+    pyr = O.pool_pyramid(O.corr_volume(f1, f2), L, round_to=rnd)
+    for kind in KINDS:
+        ref = O.convc1_relu(O.lookup_exact(pyr, g[f"coords_{kind}"], r), c["weight"], c["bias"], round_to=rnd)
+        with torch.no_grad():
+            blk = R.CorrBlock1DHip(dev(f1, dtype), dev(f2, dtype), num_levels=L, radius=r)
+            act = blk.lookup_convc1(dev(g[f"coords_{kind}"]), dev(c["weight"]), dev(c["bias"]))
+        assert act.dtype == dtype
+        assert rel(act, ref) < 2 * TOL16[dtype]
+
+
+@pytest.mark.parametrize("dtype,shape,mode", [(torch.float16, (8, 256, 96, 312), "exact"),
+                                               (torch.float32, (1, 256, 96, 128), "gridsample"),
+                                               (torch.bfloat16, (2, 128, 5, 333), "gridsample")])
+def test_lookup_convc1_equals_unfused_at_full_size(R, dtype, shape, mode):
+    """BASELINE sizes: fused == conv2d(lookup) computed with torch on the library's own lookup."""
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    B, D, H, W = shape
+    f1 = torch.randn(shape, generator=gen, device="cuda").to(dtype)
+    f2 = torch.randn(shape, generator=gen, device="cuda").to(dtype)
+    c = torch.from_numpy(O.synthetic_coords(B, H, W, seed=5)).cuda()
+    wgt = torch.randn((64, 36, 1, 1), generator=gen, device="cuda") * 0.3
+    bias = torch.randn((64,), generator=gen, device="cuda")
+    with torch.no_grad():
+        blk = R.CorrBlock1DHip(f1, f2, coord_mode=mode)
+        corr = blk(c)
+        if dtype != torch.float32:
+            ref = torch.relu(torch.nn.functional.conv2d(corr.to(dtype).float(), wgt.to(dtype).float(), bias))
+        else:
+            ref = torch.relu(torch.nn.functional.conv2d(corr.double(), wgt.double(), bias.double())).float()
+        act = blk.lookup_convc1(c, wgt, bias)
+    tol = TOL32 if dtype == torch.float32 else TOL16[dtype]
+    assert rel(act, ref.cpu().numpy()) < tol
+
+
+def test_lookup_convc1_is_forward_only(R):
+    f = torch.randn(1, 32, 2, 32, device="cuda", requires_grad=True)
+    blk = R.CorrBlock1DHip(f, f)
+    c = torch.zeros(1, 2, 2, 32, device="cuda")
+    with pytest.raises(RuntimeError):
+        blk.lookup_convc1(c, torch.zeros(64, 36, device="cuda"), torch.zeros(64, device="cuda"))
+    with torch.no_grad():
+        with pytest.raises(ValueError):
+            blk.lookup_convc1(c, torch.zeros(64, 35, device="cuda"), torch.zeros(64, device="cuda"))
 
 
 # ------------------------------------------------------------------ argument checking

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from oracle import corr_oracle as O
-from conftest import GOLDEN_CASES
+from conftest import CONVC1_CASES, GOLDEN_CASES
 
 KINDS = ["smooth", "random", "edge"]
 TOL = 1e-5          # max|a-b| / max|ref|, the fp32 bar of BASELINE.json
@@ -87,6 +87,20 @@ def test_alt_matches_reference_alt_and_reg(golden, case, kind):
     assert O.rel_to_max(out, g[f"alt_{kind}"]) < 5e-5
     out = O.alt_lookup(g["f1"], g["f2"], g[f"coords_{kind}"], L, r, O.EXACT)
     assert O.rel_to_max(out, g[f"lookup_{kind}"]) < 1e-4
+
+
+@pytest.mark.parametrize("case", CONVC1_CASES)
+@pytest.mark.parametrize("kind", ["smooth", "random", "edge"])
+def test_convc1_relu_matches_reference_motion_encoder(golden, case, kind):
+    """oracle lookup -> oracle convc1+relu against the reference's BasicMotionEncoder.convc1
+    (core/update.py:71,78) applied to its own CorrBlock1D output."""
+    g, c = golden(case), golden("convc1_" + case)
+    L, r = int(g["L"]), int(g["r"])
+    pyr = O.pool_pyramid(O.corr_volume(g["f1"], g["f2"]), L)
+    corr = O.lookup_gridsample(pyr, g[f"coords_{kind}"], r)
+    act = O.convc1_relu(corr, c["weight"], c["bias"])
+    assert O.rel_to_max(act, c[f"act_{kind}"]) < 1e-5
+    assert (c[f"act_{kind}"] == 0).any() and (c[f"act_{kind}"] > 0).any()   # the ReLU is exercised
 
 
 def test_pool_rounding_hook():
