@@ -124,6 +124,20 @@ int rc_lookup_fwd(const void* vol, const rc_layout* lay, const float* coords,
                   int coords_channels, float* out, int radius, int coord_mode, void* stream);
 
 /*
+ * SURVEY.md section 8(f) rank 2 -- the GRU iteration's coordinate glue folded into the lookup
+ * (core/raft_stereo.py:120-123 of the previous iteration and :109-111 of this one):
+ *     coords_out = coords + (delta_flow[:,0], 0)      delta_flow: float [B,2,H,W1], channel 1 ignored
+ *     flow_out   = coords_out - coords0               coords0 = pixel grid (x = w1, y = h)
+ *     out        = lookup(coords_out)
+ * coords_out/flow_out: float [B,2,H,W1]; coords_out may alias coords when coords_channels == 2.
+ * With coords_channels == 1 the y row of coords_out is the row index h.  Arithmetic is the
+ * reference's fp32 add/subtract, so results are bit-identical to the separate steps.
+ */
+int rc_lookup_fwd_update(const void* vol, const rc_layout* lay, const float* coords,
+                         int coords_channels, const float* delta_flow, float* coords_out,
+                         float* flow_out, float* out, int radius, int coord_mode, void* stream);
+
+/*
  * Adjoint of rc_lookup_fwd w.r.t. the pyramid.  grad_vol is a float pyramid (glay->dtype ==
  * RC_F32) that is ACCUMULATED into (+=): zero it once per forward pass, then call this once
  * per lookup.  Calls on one stream are ordered; no atomics are used (a pixel owns its column).

@@ -225,6 +225,27 @@ class CorrBlock1DHip:
             return _LookupFn.apply(self._token, coords, self)
         return self._lookup(coords)
 
+    def update_and_lookup(self, coords1, delta_flow):
+        """One GRU iteration's coordinate glue + lookup in a single kernel (inference):
+        `delta_flow[:,1] = 0; coords1 = coords1 + delta_flow` (core/raft_stereo.py:120-123) of the
+        previous iteration, then `corr = corr_fn(coords1); flow = coords1 - coords0` (:110-111).
+        Returns `(coords1_new, flow, corr)`; coords1 `[B,2,H,W]` fp32, delta_flow `[B,2,H,W]`."""
+        if torch.is_grad_enabled() and (self._token is not None or delta_flow.requires_grad):
+            raise RuntimeError("update_and_lookup is forward-only: call it under torch.no_grad()")
+        coords1 = _check_coords(coords1, self.B, self.H, self.W1, self.device)
+        if tuple(delta_flow.shape) != (self.B, 2, self.H, self.W1) or delta_flow.device != self.device:
+            raise ValueError(f"delta_flow must be [B={self.B}, 2, H={self.H}, W={self.W1}] on {self.device}")
+        delta = delta_flow.detach().float().contiguous()
+        with _on_device(self.device):
+            new = torch.empty((self.B, 2, self.H, self.W1), dtype=torch.float32, device=self.device)
+            flow = torch.empty_like(new)
+            out = torch.empty(self._out_shape, dtype=torch.float32, device=self.device)
+            check(lib.rc_lookup_fwd_update(self._vol_ptr, self._lay_ref, coords1.data_ptr(), coords1.shape[1],
+                                           delta.data_ptr(), new.data_ptr(), flow.data_ptr(), out.data_ptr(),
+                                           self.radius, self.coord_mode, _stream(self.device)),
+                  "rc_lookup_fwd_update")
+        return new, flow, out
+
     def lookup_convc1(self, coords, weight, bias, relu=True):
         """`F.relu(convc1(block(coords)))` (core/update.py:71,78 on the result of
         core/raft_stereo.py:110) in one kernel: the L*(2r+1)-channel tensor is never written.

@@ -20,6 +20,13 @@ namespace {
 
 constexpr int LK_THREADS = 256;  // 4 waves, each its own 64-pixel chunk
 
+// Optional coordinate update in front of a lookup (rc_lookup_fwd_update); all null for a plain lookup
+struct lk_update {
+  const float* delta;  // [B,2,H,W1]; channel 0 is added to x, channel 1 is ignored (stereo: epipolar projection)
+  float* coords_out;   // [B,2,H,W1]
+  float* flow_out;     // [B,2,H,W1]
+};
+
 // LV > 0 is a compile-time level count: the 16-byte loads of all levels are issued back to back
 // (no branch in between: lanes that do not need a block re-read one they do need), then decoded,
 // interpolated and stored.  LV == 0 takes the level count from the layout and handles one level
@@ -30,7 +37,7 @@ __global__ __launch_bounds__(LK_THREADS) void lookup_fwd_kernel(const VT* __rest
                                                                 const float* __restrict__ coords,
                                                                 int coords_channels,
                                                                 float* __restrict__ out,
-                                                                int chunks_per_row, int n_items) {
+                                                                int chunks_per_row, int n_items, lk_update upd) {
   constexpr int RB = vt_info<VT>::RB, LG = vt_info<VT>::LG;
   using WI = win_info<RB, R, MODE>;
   constexpr int NT = WI::NT, EXT = WI::EXT, NW = WI::NW, NBLK = WI::NBLK, ND = WI::ND;
@@ -48,7 +55,20 @@ __global__ __launch_bounds__(LK_THREADS) void lookup_fwd_kernel(const VT* __rest
   const int L = LV ? LV : lay.L;
   const uint32_t blk_bytes = (uint32_t)lay.pitch * 16u;  // distance between block rows of a pixel
 
-  const float x = (coords + uniform(((int64_t)b * coords_channels) * HW + (int64_t)h * lay.W1 + c0))[lane];
+  float x = (coords + uniform(((int64_t)b * coords_channels) * HW + (int64_t)h * lay.W1 + c0))[lane];
+  if (upd.delta) {  // wave-uniform: the GRU iteration's coordinate update folded into this lookup
+    // core/raft_stereo.py:120-123 (delta_flow[:,1] = 0; coords1 = coords1 + delta_flow) and :111
+    // (flow = coords1 - coords0, coords0 = the pixel grid of core/utils/utils.py coords_grid)
+    const int64_t p0 = uniform(((int64_t)b * 2) * HW + (int64_t)h * lay.W1 + c0);
+    x += (upd.delta + p0)[lane];
+    const float y = coords_channels > 1
+                        ? (coords + uniform(((int64_t)b * coords_channels + 1) * HW + (int64_t)h * lay.W1 + c0))[lane]
+                        : (float)h;
+    (upd.coords_out + p0)[lane] = x;
+    (upd.coords_out + uniform(p0 + HW))[lane] = y;
+    (upd.flow_out + p0)[lane] = x - (float)w1;
+    (upd.flow_out + uniform(p0 + HW))[lane] = y - (float)h;
+  }
   const int64_t out_u = ((int64_t)b * L * NT) * HW + (int64_t)h * lay.W1 + c0;  // wave-uniform
 
   for (int i0 = 0; i0 < L; i0 += LB) {
@@ -508,7 +528,8 @@ int dispatch_adjoint_dense(const adj_lists& lists, const adj_dims& d, void* dC, 
 }
 
 template <typename VT, int R, int MODE>
-int launch_fwd_mode(const void* vol, rc_dev_layout d, const float* coords, int cc, float* out, hipStream_t st) {
+int launch_fwd_mode(const void* vol, rc_dev_layout d, const float* coords, int cc, float* out, hipStream_t st,
+                    const lk_update& upd) {
   using WI = win_info<vt_info<VT>::RB, R, MODE>;
   set_row_bias(d, vt_info<VT>::RB, WI::NW);
   const int chunks = (d.W1 + 63) / 64;
@@ -516,32 +537,32 @@ int launch_fwd_mode(const void* vol, rc_dev_layout d, const float* coords, int c
   const int blocks = (n_items + (LK_THREADS / 64) - 1) / (LK_THREADS / 64);
   if (R == 4 && d.L == 4)  // the model's configuration: all levels' loads in flight together
     hipLaunchKernelGGL((lookup_fwd_kernel<VT, R, MODE, (R == 4 ? 4 : 0)>), dim3(blocks), dim3(LK_THREADS), 0, st,
-                       (const VT*)vol, d, coords, cc, out, chunks, n_items);
+                       (const VT*)vol, d, coords, cc, out, chunks, n_items, upd);
   else
     hipLaunchKernelGGL((lookup_fwd_kernel<VT, R, MODE, 0>), dim3(blocks), dim3(LK_THREADS), 0, st, (const VT*)vol,
-                       d, coords, cc, out, chunks, n_items);
+                       d, coords, cc, out, chunks, n_items, upd);
   return rc_check_launch("rc_lookup_fwd");
 }
 
 template <typename VT, int R>
 int launch_fwd(const void* vol, const rc_dev_layout& d, const float* coords, int cc, float* out, int mode,
-               hipStream_t st) {
-  return mode == RC_COORD_EXACT ? launch_fwd_mode<VT, R, RC_COORD_EXACT>(vol, d, coords, cc, out, st)
-                                : launch_fwd_mode<VT, R, RC_COORD_GRIDSAMPLE>(vol, d, coords, cc, out, st);
+               hipStream_t st, const lk_update& upd) {
+  return mode == RC_COORD_EXACT ? launch_fwd_mode<VT, R, RC_COORD_EXACT>(vol, d, coords, cc, out, st, upd)
+                                : launch_fwd_mode<VT, R, RC_COORD_GRIDSAMPLE>(vol, d, coords, cc, out, st, upd);
 }
 
 template <typename VT>
 int dispatch_fwd_radius(const void* vol, const rc_dev_layout& d, const float* coords, int cc, float* out,
-                        int radius, int mode, hipStream_t st) {
+                        int radius, int mode, hipStream_t st, const lk_update& upd) {
   switch (radius) {
-    case 1: return launch_fwd<VT, 1>(vol, d, coords, cc, out, mode, st);
-    case 2: return launch_fwd<VT, 2>(vol, d, coords, cc, out, mode, st);
-    case 3: return launch_fwd<VT, 3>(vol, d, coords, cc, out, mode, st);
-    case 4: return launch_fwd<VT, 4>(vol, d, coords, cc, out, mode, st);
-    case 5: return launch_fwd<VT, 5>(vol, d, coords, cc, out, mode, st);
-    case 6: return launch_fwd<VT, 6>(vol, d, coords, cc, out, mode, st);
-    case 7: return launch_fwd<VT, 7>(vol, d, coords, cc, out, mode, st);
-    case 8: return launch_fwd<VT, 8>(vol, d, coords, cc, out, mode, st);
+    case 1: return launch_fwd<VT, 1>(vol, d, coords, cc, out, mode, st, upd);
+    case 2: return launch_fwd<VT, 2>(vol, d, coords, cc, out, mode, st, upd);
+    case 3: return launch_fwd<VT, 3>(vol, d, coords, cc, out, mode, st, upd);
+    case 4: return launch_fwd<VT, 4>(vol, d, coords, cc, out, mode, st, upd);
+    case 5: return launch_fwd<VT, 5>(vol, d, coords, cc, out, mode, st, upd);
+    case 6: return launch_fwd<VT, 6>(vol, d, coords, cc, out, mode, st, upd);
+    case 7: return launch_fwd<VT, 7>(vol, d, coords, cc, out, mode, st, upd);
+    case 8: return launch_fwd<VT, 8>(vol, d, coords, cc, out, mode, st, upd);
   }
   rc_set_error("radius %d outside 1..%d", radius, RC_MAX_RADIUS);
   return RC_EUNSUPPORTED;
@@ -568,19 +589,35 @@ int launch_bwd(const float* coords, int cc, const float* gout, float* gvol, cons
 
 }  // namespace
 
-extern "C" int rc_lookup_fwd(const void* vol, const rc_layout* lay, const float* coords, int coords_channels,
-                             float* out, int radius, int coord_mode, void* stream) {
+static int lookup_fwd_any(const void* vol, const rc_layout* lay, const float* coords, int coords_channels,
+                          float* out, int radius, int coord_mode, void* stream, const lk_update& upd) {
   int rc = check_common(lay, vol, coords, out, coords_channels, radius, coord_mode);
   if (rc) return rc;
   const rc_dev_layout d = rc_to_dev(lay);
   hipStream_t st = (hipStream_t)stream;
   switch (lay->dtype) {
-    case RC_F32: return dispatch_fwd_radius<float>(vol, d, coords, coords_channels, out, radius, coord_mode, st);
-    case RC_F16: return dispatch_fwd_radius<rc_half>(vol, d, coords, coords_channels, out, radius, coord_mode, st);
-    case RC_BF16: return dispatch_fwd_radius<rc_bf16>(vol, d, coords, coords_channels, out, radius, coord_mode, st);
+    case RC_F32:
+      return dispatch_fwd_radius<float>(vol, d, coords, coords_channels, out, radius, coord_mode, st, upd);
+    case RC_F16:
+      return dispatch_fwd_radius<rc_half>(vol, d, coords, coords_channels, out, radius, coord_mode, st, upd);
+    case RC_BF16:
+      return dispatch_fwd_radius<rc_bf16>(vol, d, coords, coords_channels, out, radius, coord_mode, st, upd);
   }
   rc_set_error("unknown pyramid dtype %d", lay->dtype);
   return RC_EUNSUPPORTED;
+}
+
+extern "C" int rc_lookup_fwd(const void* vol, const rc_layout* lay, const float* coords, int coords_channels,
+                             float* out, int radius, int coord_mode, void* stream) {
+  return lookup_fwd_any(vol, lay, coords, coords_channels, out, radius, coord_mode, stream, lk_update{});
+}
+
+extern "C" int rc_lookup_fwd_update(const void* vol, const rc_layout* lay, const float* coords,
+                                    int coords_channels, const float* delta_flow, float* coords_out,
+                                    float* flow_out, float* out, int radius, int coord_mode, void* stream) {
+  RC_REQUIRE(delta_flow && coords_out && flow_out, RC_EINVAL, "null pointer argument");
+  const lk_update upd = {delta_flow, coords_out, flow_out};
+  return lookup_fwd_any(vol, lay, coords, coords_channels, out, radius, coord_mode, stream, upd);
 }
 
 extern "C" int rc_lookup_bwd(const float* coords, int coords_channels, const float* grad_out,

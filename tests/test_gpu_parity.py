@@ -404,6 +404,35 @@ def test_lookup_convc1_is_forward_only(R):
             blk.lookup_convc1(c, torch.zeros(64, 35, device="cuda"), torch.zeros(64, device="cuda"))
 
 
+# ------------------------------------------------------------------ coordinate glue in the lookup
+@pytest.mark.parametrize("dtype,shape", [(torch.float32, (2, 64, 3, 45)), (torch.float16, (2, 256, 7, 312)),
+                                          (torch.bfloat16, (1, 32, 2, 130))])
+def test_update_and_lookup_is_bit_identical_to_the_separate_steps(R, dtype, shape):
+    """core/raft_stereo.py:109-123 with torch ops + the library's lookup, against the one-kernel form."""
+    gen = torch.Generator(device="cuda").manual_seed(21)
+    B, D, H, W = shape
+    f1 = torch.randn(shape, generator=gen, device="cuda").to(dtype)
+    f2 = torch.randn(shape, generator=gen, device="cuda").to(dtype)
+    coords1 = torch.from_numpy(O.synthetic_coords(B, H, W, seed=8)).cuda()
+    ys, xs = torch.meshgrid(torch.arange(H, device="cuda"), torch.arange(W, device="cuda"), indexing="ij")
+    coords0 = torch.stack([xs, ys], dim=0).float()[None].repeat(B, 1, 1, 1)       # utils.coords_grid
+    with torch.no_grad():
+        blk = R.CorrBlock1DHip(f1, f2)
+        for it in range(3):
+            delta = torch.randn((B, 2, H, W), generator=gen, device="cuda") * 2.5
+            ref_delta = delta.clone()
+            ref_delta[:, 1] = 0.0
+            ref_coords = coords1 + ref_delta
+            ref_corr, ref_flow = blk(ref_coords), ref_coords - coords0
+            new, flow, corr = blk.update_and_lookup(coords1, delta)
+            assert torch.equal(new, ref_coords) and torch.equal(flow, ref_flow) and torch.equal(corr, ref_corr)
+            coords1 = new
+        # 1-channel coords (what CorrBlockFast1D passes, core/corr.py:48): y comes out as the row index
+        new, flow, corr = blk.update_and_lookup(coords1[:, :1].contiguous(), delta)
+        assert torch.equal(new[:, 1], coords0[:, 1]) and torch.equal(flow[:, 1], torch.zeros_like(flow[:, 1]))
+        assert torch.equal(corr, blk(new))
+
+
 # ------------------------------------------------------------------ argument checking
 def test_argument_errors(R):
     f = torch.randn(1, 32, 2, 32, device="cuda")
