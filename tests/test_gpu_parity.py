@@ -335,6 +335,47 @@ def test_alt_more_lookups_than_one_fused_call(R):
     assert rel(many1, (70 * f1.grad).cpu().numpy()) < 1e-5 and rel(many2, (70 * f2.grad).cpu().numpy()) < 1e-5
 
 
+# ------------------------------------------------------------------ every compiled radius / level count
+@pytest.mark.parametrize("L,r", [(1, 1), (1, 8), (2, 2), (3, 5), (3, 6), (4, 7), (4, 8), (2, 4), (4, 1)])
+def test_every_radius_and_level_count_against_the_oracle(R, L, r):
+    """The golden vectors hold (4,4) and (2,3); the oracle (pinned by them) covers the other template
+    instances: reg forward in both coordinate modes, fp32 and fp16, alt, the fused adjoint, convc1."""
+    rng = np.random.default_rng(100 * L + r)
+    B, D, H, W1, W2 = 1, 32, 2, 40, 70
+    f1 = rng.standard_normal((B, D, H, W1)).astype(np.float32)
+    f2 = rng.standard_normal((B, D, H, W2)).astype(np.float32)
+    x = rng.uniform(-r - 2, W2 + r + 2, size=(B, 1, H, W1)).astype(np.float32)
+    coords = np.concatenate([x, np.zeros_like(x)], axis=1)
+    K = L * (2 * r + 1)
+    G = rng.standard_normal((B, K, H, W1)).astype(np.float32)
+    pyr = O.pool_pyramid(O.corr_volume(f1, f2), L)
+    widths = [p.shape[-1] for p in pyr]
+    for mode, name in ((O.GRIDSAMPLE, "gridsample"), (O.EXACT, "exact")):
+        ref = O.lookup(pyr, coords, r, mode)
+        t1, t2 = dev(f1).requires_grad_(True), dev(f2).requires_grad_(True)
+        blk = R.CorrBlock1DHip(t1, t2, num_levels=L, radius=r, coord_mode=name)
+        out = blk(dev(coords))
+        assert rel(out, ref) < TOL32
+        (out * dev(G)).sum().backward()
+        d1, d2 = O.corr_volume_bwd(O.pool_pyramid_bwd(O.lookup_bwd(coords, G, widths, r, mode)), f1, f2)
+        assert rel(t1.grad, d1) < TOL32 and rel(t2.grad, d2) < TOL32
+        if r <= 6:
+            alt = R.AltCorrBlock1DHip(dev(f1), dev(f2), num_levels=L, radius=r, coord_mode=name)(dev(coords))
+            assert rel(alt, ref) < TOL32
+        if r <= 7:
+            w = rng.standard_normal((64, K)).astype(np.float32)
+            bvec = rng.standard_normal(64).astype(np.float32)
+            with torch.no_grad():
+                act = R.CorrBlock1DHip(dev(f1), dev(f2), num_levels=L, radius=r, coord_mode=name).lookup_convc1(
+                    dev(coords), dev(w), dev(bvec))
+            assert rel(act, O.convc1_relu(ref, w, bvec)) < TOL32
+    h1, h2 = f1.astype(np.float16).astype(np.float32), f2.astype(np.float16).astype(np.float32)
+    rnd = lambda a: a.astype(np.float16).astype(np.float32)
+    ref16 = O.lookup_exact(O.pool_pyramid(O.corr_volume(h1, h2), L, round_to=rnd), coords, r)
+    out16 = R.CorrBlock1DHip(dev(h1, torch.float16), dev(h2, torch.float16), num_levels=L, radius=r)(dev(coords))
+    assert rel(out16, ref16) < TOL16[torch.float16]
+
+
 # ------------------------------------------------------------------ fused lookup + convc1 (SURVEY 8f rank 1)
 @pytest.mark.parametrize("case", CONVC1_CASES)
 @pytest.mark.parametrize("kind", KINDS)
