@@ -189,7 +189,10 @@ template <typename VT> struct out_map {
   }
   __device__ __forceinline__ bool ok(int i, int col, int G) const { return col < W1 && (uint32_t)G < nb[i]; }
   __device__ __forceinline__ void store16(int i, int col, int G, uint32_t a, uint32_t b, uint32_t c, uint32_t d) const {
-    if (ok(i, col, G)) *reinterpret_cast<uint4*>(base[i] + offset(i, col, G)) = make_uint4(a, b, c, d);
+    if (ok(i, col, G)) {
+      const u4v v = {a, b, c, d};
+      __builtin_nontemporal_store(v, reinterpret_cast<u4v*>(base[i] + offset(i, col, G)));
+    }
   }
   __device__ __forceinline__ void store8(int i, int col, int G, int half, uint32_t a, uint32_t b) const {
     if (ok(i, col, G)) *reinterpret_cast<uint2*>(base[i] + (offset(i, col, G) + 8u * half)) = make_uint2(a, b);
@@ -378,6 +381,7 @@ __global__ __launch_bounds__(BT) void build_kernel(const T* __restrict__ f1, con
     stage_store<T, C::PF>(regs, ldsF);
     __syncthreads();
     if (c + 1 < n_chunks) stage_load<T, FAST>(regs, f2row, ks2, W2, n0 + C::TN, D);
+    if (cw >= W1) continue;  // wave-uniform: a wave past the row end only helps with the staging
 
     f4v acc[C::NRT][2];
 #pragma unroll
