@@ -9,7 +9,9 @@ if ROOT not in sys.path:
 
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 _NPZ = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz"))
-GOLDEN_CASES = [n for n in _NPZ if not n.startswith("convc1_")]
+GOLDEN_CASES = [n for n in _NPZ if not n.startswith(("convc1_", "model_"))]
+# what crossed the correlation block's interface in a forward pass of the reference's whole model
+MODEL_CASE = "model_b1_h24_w32"
 # cases that also have the reference's relu(convc1(lookup)) activations (make_golden_convc1.py)
 CONVC1_CASES = [n[len("convc1_"):] for n in _NPZ if n.startswith("convc1_")]
 

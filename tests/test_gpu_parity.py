@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from oracle import corr_oracle as O
-from conftest import CONVC1_CASES, GOLDEN_CASES
+from conftest import CONVC1_CASES, GOLDEN_CASES, MODEL_CASE
 
 pytestmark = pytest.mark.gpu
 
@@ -118,6 +118,34 @@ def test_alt_backward_fp32_matches_reference_autograd(R, golden, case):
     sum((o * dev(g[f"gout_{k}"])).sum() for o, k in zip(outs, KINDS)).backward()
     assert rel(f1.grad, g["df1_multi"]) < TOL32
     assert rel(f2.grad, g["df2_multi"]) < TOL32
+
+
+def test_replay_of_the_reference_model_run(R, golden):
+    """The block inside a forward pass of the reference's RAFTStereo: its recorded feature maps in,
+    its recorded per-iteration outputs back -- reg_hip, alt_hip, the fused convc1 and the fused
+    coordinate update, all through the C-ABI."""
+    g = golden(MODEL_CASE)
+    L, r, n = int(g["L"]), int(g["r"]), int(g["n_iters"])
+    w, bias = dev(g["convc1_weight"]), dev(g["convc1_bias"])
+    with torch.no_grad():
+        reg = R.make_corr_fn("reg_hip", dev(g["f1"]), dev(g["f2"]), radius=r, num_levels=L)
+        alt = R.make_corr_fn("alt_hip", dev(g["f1"]), dev(g["f2"]), radius=r, num_levels=L)
+        coords0 = dev(g["coords_0"])              # initialize_flow: the pixel grid (core/raft_stereo.py:50-51)
+        coords1 = coords0
+        for k in range(n):
+            c = dev(g[f"coords_{k}"])
+            assert rel(reg(c), g[f"corr_{k}"]) < TOL32
+            assert rel(alt(c), g[f"corr_{k}"]) < TOL32
+            assert rel(reg.lookup_convc1(c, w, bias), g[f"act_{k}"]) < TOL32
+            if k:
+                # the step the GRU took, replayed through the fused update: same coords, flow and corr
+                delta = torch.zeros_like(c)
+                delta[:, 0] = c[:, 0] - coords1[:, 0]
+                delta[:, 1] = 123.0              # the reference zeroes this channel (core/raft_stereo.py:120)
+                new, flow, corr = reg.update_and_lookup(coords1, delta)
+                assert rel(new, g[f"coords_{k}"]) < 1e-6 and rel(corr, g[f"corr_{k}"]) < TOL32
+                assert torch.equal(flow, new - coords0)
+                coords1 = new
 
 
 # ------------------------------------------------------------------ MFMA kernel vs the naive kernel

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from oracle import corr_oracle as O
-from conftest import CONVC1_CASES, GOLDEN_CASES
+from conftest import CONVC1_CASES, GOLDEN_CASES, MODEL_CASE
 
 KINDS = ["smooth", "random", "edge"]
 TOL = 1e-5          # max|a-b| / max|ref|, the fp32 bar of BASELINE.json
@@ -101,6 +101,21 @@ def test_convc1_relu_matches_reference_motion_encoder(golden, case, kind):
     act = O.convc1_relu(corr, c["weight"], c["bias"])
     assert O.rel_to_max(act, c[f"act_{kind}"]) < 1e-5
     assert (c[f"act_{kind}"] == 0).any() and (c[f"act_{kind}"] > 0).any()   # the ReLU is exercised
+
+
+def test_oracle_replays_the_reference_model_run(golden):
+    """Feature maps, per-iteration coords, block outputs and relu(convc1(corr)) recorded inside a
+    forward pass of the reference's RAFTStereo (tests/golden/make_golden_model.py)."""
+    g = golden(MODEL_CASE)
+    L, r = int(g["L"]), int(g["r"])
+    pyr = O.pool_pyramid(O.corr_volume(g["f1"], g["f2"]), L)
+    for k in range(int(g["n_iters"])):
+        corr = O.lookup_gridsample(pyr, g[f"coords_{k}"], r)
+        assert O.rel_to_max(corr, g[f"corr_{k}"]) < 1e-5
+        assert O.rel_to_max(O.convc1_relu(corr, g["convc1_weight"], g["convc1_bias"]), g[f"act_{k}"]) < 1e-5
+        if k:
+            assert not np.array_equal(g[f"coords_{k}"], g[f"coords_{k - 1}"])     # the GRU moved the coords
+            assert np.array_equal(g[f"coords_{k}"][:, 1], g["coords_0"][:, 1])    # only along x
 
 
 def test_pool_rounding_hook():
