@@ -149,15 +149,16 @@ class _LookupFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, token, coords, block):
         ctx.block = block
-        ctx.save_for_backward(coords)
+        ctx.coords = coords       # detached fp32 (see _check_coords): kept as is, no saved-tensor bookkeeping
         return block._lookup(coords)
 
     @staticmethod
     def backward(ctx, grad_out):
         # nothing is computed here: the build's backward, which autograd runs after every lookup's,
         # takes all (coords, grad_out) pairs in one fused call
-        (coords,) = ctx.saved_tensors
-        ctx.block._pending.append((coords, grad_out.float().contiguous()))        # core/corr.py:27
+        if grad_out.dtype is not torch.float32 or not grad_out.is_contiguous():
+            grad_out = grad_out.float().contiguous()                              # core/corr.py:27
+        ctx.block._pending.append((ctx.coords, grad_out))
         return None, None, None     # autograd still runs the build's backward once all lookups have
 
 
