@@ -172,6 +172,31 @@ def fused_convc1(step, cfg, device, n=50):
                 fused_lookup_convc1_gbps=round(alg / (fused * 1e-6) / 1e9, 1))
 
 
+def hip_graph_step(step, n=50):
+    """The same step (build/prepare + lookups) captured once in a HIP graph and replayed: what a
+    caller that captures its GRU loop pays per pair batch once launch overhead is gone.  Reported
+    beside `ms_per_step` (which stays the eager number); the library needs nothing special for this:
+    it neither allocates nor synchronises."""
+    with torch.no_grad():
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step.run(record=False)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step.run(record=False)
+        for _ in range(3):
+            graph.replay()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            graph.replay()
+        b.record()
+        b.synchronize()
+    return dict(hip_graph_ms_per_step=round(a.elapsed_time(b) / n, 4))
+
+
 def cpu_baseline(cfg, budget_s=15.0):
     """The reference's reg path (torch ops port, oracle/reg_torch.py) on this host's cores, on a
     bounded sample of the same workload: ONE pair of this shape in fp32, repeated for ~budget_s."""
@@ -288,6 +313,8 @@ def main():
 
     if not is_alt and not cfg["train"] and rank == 0:
         extra.update(fused_convc1(step, cfg, device))      # after the timed region: not part of `value`
+    if not cfg["train"] and rank == 0:
+        extra.update(hip_graph_step(step))
 
     roof["traffic"] = measured_traffic(args.workload, cfg["batch"], roof["kernel"])
     line = {

@@ -502,6 +502,43 @@ def test_update_and_lookup_is_bit_identical_to_the_separate_steps(R, dtype, shap
         assert torch.equal(corr, blk(new))
 
 
+# ------------------------------------------------------------------ HIP graph capture
+def test_build_and_lookups_replay_from_a_hip_graph(R):
+    """The library neither allocates nor synchronises, so a caller can capture its GRU loop: the
+    replayed graph gives the eager results (reg_hip with the fused update, alt_hip, fused convc1)."""
+    gen = torch.Generator(device="cuda").manual_seed(31)
+    f1 = torch.randn((1, 256, 12, 80), generator=gen, device="cuda").half()
+    f2 = torch.randn((1, 256, 12, 80), generator=gen, device="cuda").half()
+    coords = torch.from_numpy(O.synthetic_coords(1, 12, 80, seed=4)).cuda()
+    delta = torch.randn((1, 2, 12, 80), generator=gen, device="cuda")
+    w = torch.randn((64, 36), generator=gen, device="cuda") * 0.2
+    bias = torch.randn((64,), generator=gen, device="cuda")
+
+    def loop():
+        reg, alt = R.CorrBlock1DHip(f1, f2), R.AltCorrBlock1DHip(f1, f2)
+        c, outs = coords, []
+        for _ in range(3):
+            c, flow, corr = reg.update_and_lookup(c, delta)
+            outs += [corr, flow, alt(c), reg.lookup_convc1(c, w, bias).float()]
+        return outs
+
+    with torch.no_grad():
+        eager = [o.clone() for o in loop()]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            loop()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            captured = loop()
+        for o in captured:
+            o.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(captured, eager))
+
+
 # ------------------------------------------------------------------ argument checking
 def test_argument_errors(R):
     f = torch.randn(1, 32, 2, 32, device="cuda")
