@@ -317,8 +317,17 @@ __device__ __forceinline__ void adjoint_accumulate(float* row, int Wi, float xi,
       tw[k + 3] += dlt > 0 ? a1 : 0.f;
     }
   }
-  // branch-free: entries outside the image add their (unused) value to the sink cell row[Wi]
   float cur[NW];
+  if (!__any(wbase < 0 || wbase + NW > Wi)) {
+    // every window of the wave lies inside the image: one base address, constant offsets
+    float* win = row + wbase;
+#pragma unroll
+    for (int m = 0; m < NW; ++m) cur[m] = win[m];
+#pragma unroll
+    for (int m = 0; m < NW; ++m) win[m] = cur[m] + tw[m];
+    return;
+  }
+  // branch-free: entries outside the image add their (unused) value to the sink cell row[Wi]
   int idx[NW];
 #pragma unroll
   for (int m = 0; m < NW; ++m) {
@@ -381,17 +390,21 @@ __global__ __launch_bounds__(RC_MAX_LEVELS * TP) void adjoint_dense_kernel(adj_l
     const float inv = 1.0f / (float)(1 << lvl);
     const float wm1 = (float)(Wi - 1);
     float* row = acc + d.base[lvl] + p * d.pitch[lvl];
-    const int64_t coff = ((int64_t)b * d.cc) * HW + (int64_t)h * d.W1 + w1;
-    const int64_t goff = (((int64_t)b * L + lvl) * NT) * HW + (int64_t)h * d.W1 + w1;
+    // wave-uniform bases + 32-bit lane offsets (computed once): a fetch costs no address arithmetic
+    const int64_t cu = uniform(((int64_t)b * d.cc) * HW + (int64_t)h * d.W1 + c0);
+    const int64_t gu = uniform(((int64_t)b * L * NT) * HW + (int64_t)h * d.W1 + c0);
+    uint32_t voff[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) voff[k] = (uint32_t)(lvl * NT + k) * (uint32_t)HW + (uint32_t)p;
     // PD lookups' planes are in flight at any time: with the pixel tile bounded by LDS only a few
     // waves fit on a CU, so the latency has to be covered from inside the wave
     constexpr int PD = 4;
     float xs[PD], gs[PD][NT];
     auto fetch = [&](int t, int slot) {  // t is block-uniform: the list entries come through scalar loads
-      xs[slot] = ((rc_gptr)lists.coords[t])[coff];
-      rc_gptr gp = ((rc_gptr)lists.gout[t]) + goff;
+      xs[slot] = (((rc_gptr)lists.coords[t]) + cu)[(uint32_t)p];
+      rc_gptr gp = ((rc_gptr)lists.gout[t]) + gu;
 #pragma unroll
-      for (int k = 0; k < NT; ++k) gs[slot][k] = gp[(int64_t)k * HW];
+      for (int k = 0; k < NT; ++k) gs[slot][k] = gp[voff[k]];
     };
     // every fetch is unconditional (past the end it re-reads the last lookup, a cache hit): a load
     // under a branch would make the compiler wait for all loads at every join
@@ -655,6 +668,8 @@ extern "C" int rc_lookup_bwd_dense(const float* const* coords_list, const float*
   int rc = check_common(glay, dense_grad, coords_list[0], grad_out_list[0], coords_channels, radius, coord_mode);
   if (rc) return rc;
   RC_REQUIRE(D >= 1 && D < (1 << 20), RC_EINVAL, "bad feature depth D=%lld", (long long)D);
+  RC_REQUIRE((int64_t)glay->L * (2 * radius + 1) * glay->H * glay->W1 < (1ll << 29), RC_EINVAL,
+             "one image's gradient planes exceed the 32-bit lane offset range");
   adj_lists lists;
   for (int t = 0; t < RC_MAX_FUSED_LOOKUPS; ++t) {
     const int s = t < n_lookups ? t : 0;
