@@ -258,6 +258,36 @@ __global__ __launch_bounds__(GT) void gemm_rows_kernel(const T* __restrict__ fea
   }
 
   // lane (g, li): columns n0 + 16 y + 4 g + {0..3} of channel mb + 32 wave + 16 x + li
+  if constexpr (C::IS16) {
+    if ((N & 1) == 0) {  // rows of the result start on dword boundaries
+      // 16-bit results go through LDS (the feature image is free now) so that they leave as 16-byte
+      // pieces, 8 lanes per 128-byte run of a channel row, instead of 8-byte pieces of 16 rows at once
+      static_assert(TS + 8 <= C::PA && TMF * C::PA <= C::FEAT_ELEMS, "the output tile reuses the feature image");
+      typedef T t4v __attribute__((ext_vector_type(4)));
+      __syncthreads();  // every wave has finished reading featI
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+          *reinterpret_cast<t4v*>(featI + (wave * 32 + 16 * x + li) * C::PA + 16 * y + 4 * g) =
+              __builtin_convertvector(acc[y][x], t4v);
+      __syncthreads();
+      const int n = n0 + sseg * C::EPS;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = srow + 64 * j, m = mb + r;
+        if (m >= M || n >= N) continue;
+        T* dst = out + (((int64_t)b * M + m) * H + h) * N + n;
+        const T* src = featI + r * C::PA + sseg * C::EPS;
+        if (n + C::EPS <= N) {
+          *reinterpret_cast<u4v_a4*>(dst) = *reinterpret_cast<const u4v*>(src);
+        } else {
+          for (int e = 0; n + e < N; ++e) dst[e] = src[e];
+        }
+      }
+      return;
+    }
+  }
   const bool vec_out = (N % 4 == 0);
 #pragma unroll
   for (int x = 0; x < 2; ++x) {
