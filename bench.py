@@ -313,7 +313,7 @@ def main():
 
     if not is_alt and not cfg["train"] and rank == 0:
         extra.update(fused_convc1(step, cfg, device))      # after the timed region: not part of `value`
-    if not cfg["train"] and rank == 0:
+    if not cfg["train"] and world == 1:       # side metric; kept out of multi-rank runs (no capture beside RCCL)
         extra.update(hip_graph_step(step))
 
     roof["traffic"] = measured_traffic(args.workload, cfg["batch"], roof["kernel"])
