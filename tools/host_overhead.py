@@ -45,3 +45,40 @@ with torch.no_grad():
         pass
     print("_on_device ctx           %.2f us" % bench(lambda: C._on_device(dev).__enter__()))
     print("is_grad_enabled          %.2f us" % bench(torch.is_grad_enabled))
+
+# the autograd path (training): Function.apply per lookup, then the deferred backward
+g1 = torch.randn(8, 256, 80, 180, device=dev).bfloat16().requires_grad_(True)
+g2 = torch.randn(8, 256, 80, 180, device=dev).bfloat16().requires_grad_(True)
+c8 = torch.zeros(8, 2, 80, 180, device=dev)
+c8[:, 0] = torch.arange(180, device=dev).float() - 3.3
+blk = R.CorrBlock1DHip(g1, g2)
+print("autograd __call__        %.2f us (kernel ~8.5 us)" % bench(lambda: blk(c8), n=2000))
+blk._pending.clear()
+gout = torch.randn(8, 36, 80, 180, device=dev)
+
+
+def train_step():
+    b = R.CorrBlock1DHip(g1, g2)
+    outs = [b(c8) for _ in range(22)]
+    g1.grad = g2.grad = None
+    torch.autograd.backward(outs, [gout] * 22)
+
+
+for _ in range(5):
+    train_step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(50):
+    train_step()
+t1 = time.perf_counter()           # host time to ENQUEUE 50 steps (no sync in between)
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print("train step: host enqueue %.1f us, with GPU drain %.1f us" % ((t1 - t0) / 50 * 1e6, (t2 - t0) / 50 * 1e6))
+import cProfile, pstats
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(20):
+    train_step()
+pr.disable()
+torch.cuda.synchronize()
+pstats.Stats(pr).sort_stats("tottime").print_stats(14)
