@@ -9,8 +9,8 @@
 // lane (g, li) = channels kc*KCH + [g*KCH/4, (g+1)*KCH/4) of position 16*pb + li:
 //   element offset = ((row*nblk + pb)*nkc + kc)*64*EL + (g*16 + li)*EL + e,  EL = 16 B / elemsize.
 // An operand load is then one contiguous 1 KiB run per wave instruction (8 cache lines instead of 64).
-// rc_alt_fwd (every iteration): a wave owns 16 consecutive pixels of one image row.  Per level it
-// takes the union of the pixels' tap windows, and for each 16-wide block of right-image
+// rc_alt_fwd (every iteration): a workgroup owns 16 consecutive pixels of one image row, one wave
+// per pyramid level.  The wave takes the union of the pixels' tap windows at its level, and for each 16-wide block of right-image
 // positions in it forms the 16x16 product tile  f2t_i[block] . f1t[pixels]^T  on the matrix
 // cores (K = Dp); MFMA rows are w2, so a lane holds 4 consecutive w2 of one pixel; it drops those
 // inside the pixel's own window into LDS, from where the pixel's 2r+1 taps are interpolated.
@@ -138,18 +138,20 @@ __global__ __launch_bounds__(256) void alt_fwd_kernel(const T* __restrict__ f1t,
   constexpr int EL = 16 / (int)sizeof(T);
   constexpr int KCH = 4 * EL;                               // K elements consumed per operand load
   constexpr int NKC = DMAX / KCH;
-  // a pixel's window of correlation values, per wave and level: slot j <-> w2 = base + j
-  __shared__ float win[4][RC_MAX_LEVELS][16][PITCH];
+  // a pixel's window of correlation values at the wave's level: slot j <-> w2 = base + j
+  __shared__ float win[RC_MAX_LEVELS][16][PITCH];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, li = lane & 15;
-  // A workgroup owns 64 consecutive pixels of one image row.  Workgroup ids that agree mod 8 run on
-  // the same XCD: they get the same rows, so a row of fmap2 goes through one L2 only.
+  // A workgroup owns 16 consecutive pixels of one image row, one wave per pyramid level (a level
+  // needs 1-3 operand blocks: short dependent chains, and the four waves share the pixels' operand
+  // through the L1).  Workgroup ids that agree mod 8 run on the same XCD: they get the same rows, so
+  // a row of fmap2 goes through one L2 only.
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int bh = (slot / blocks_per_row) * 8 + xcd;
-  const int pb1 = (slot % blocks_per_row) * 4 + wave;  // the wave's block of 16 pixels
+  const int pb1 = slot % blocks_per_row;  // the workgroup's block of 16 pixels; wave = pyramid level
   const int w1 = pb1 * 16 + li;
-  if (bh >= n_rows || pb1 * 16 >= lay.W1) return;  // wave-uniform
+  if (bh >= n_rows || pb1 * 16 >= lay.W1 || wave >= lay.L) return;  // wave-uniform
   const int b = bh / lay.H, h = bh - b * lay.H;
   const bool live = w1 < lay.W1;
   const int w1c = live ? w1 : lay.W1 - 1;
@@ -169,14 +171,13 @@ __global__ __launch_bounds__(256) void alt_fwd_kernel(const T* __restrict__ f1t,
   }
   const float x = coords[((int64_t)b * coords_channels) * HW + (int64_t)h * lay.W1 + w1c];
 
-  float inv = 1.0f;
-  for (int i = 0; i < lay.L; ++i) {
+  {
+    const int i = wave;
     const int Wi = lay.width[i];
-    const float xi = x * inv;
-    inv *= 0.5f;
+    const float xi = x / (float)(1 << i);
     const float xf = floorf(xi);
     const int base = rc_safe_int(xf) - R - EXT;
-    float* mywin = &win[wave][i][li][0];
+    float* mywin = &win[i][li][0];
 
     // union of the 16 pixels' windows (all 64 lanes take part; the 4 groups hold copies)
     int lo = live ? base : (1 << 30), hi = live ? base + NS - 1 : -(1 << 30);
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(256) void alt_fwd_kernel(const T* __restrict__ f1t,
 template <typename T, int R>
 int launch_alt(const void* f1t, const void* f2t, const alt_dev_layout& d, const float* coords, int cc,
                float* out, int mode, hipStream_t st) {
-  const int bpr = (d.W1 + 63) / 64;
+  const int bpr = (d.W1 + 15) / 16;
   const int n_rows = d.B * d.H;
   const int64_t nb = (int64_t)((n_rows + 7) / 8) * 8 * bpr;
   RC_REQUIRE(nb < (1ll << 31), RC_EINVAL, "too many pixels");
