@@ -404,6 +404,51 @@ def test_every_radius_and_level_count_against_the_oracle(R, L, r):
     assert rel(out16, ref16) < TOL16[torch.float16]
 
 
+def _random_geometries(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        L = int(rng.integers(1, 5))
+        W2 = int(rng.integers(max(2 << (L - 1), 3), 150))
+        out.append((int(rng.integers(1, 4)), int(rng.choice([1, 7, 24, 32, 50, 64, 100, 256])), int(rng.integers(1, 5)),
+                    int(rng.integers(1, 140)), W2, L, int(rng.integers(1, 9))))
+    return out
+
+
+@pytest.mark.parametrize("geom", _random_geometries(14, seed=2025) +
+                         [(1, 32, 1, 1, 16, 4, 4), (2, 7, 2, 5, 3, 1, 1), (1, 64, 1, 130, 17, 4, 8), (1, 256, 1, 64, 16, 4, 4)])
+def test_ragged_geometries_against_the_oracle(R, geom):
+    """Seeded random shapes: widths that are no multiple of anything, W1 != W2, single pixels and
+    rows, feature depths that miss the MFMA chunk, every level count and radius."""
+    B, D, H, W1, W2, L, r = geom
+    rng = np.random.default_rng(hash(geom) % (1 << 31))
+    f1 = rng.standard_normal((B, D, H, W1)).astype(np.float32)
+    f2 = rng.standard_normal((B, D, H, W2)).astype(np.float32)
+    x = rng.uniform(-r - 3, W2 + r + 3, size=(B, 1, H, W1)).astype(np.float32)
+    coords = np.concatenate([x, np.zeros_like(x)], axis=1)
+    G = rng.standard_normal((B, L * (2 * r + 1), H, W1)).astype(np.float32)
+    pyr = O.pool_pyramid(O.corr_volume(f1, f2), L)
+    widths = [p.shape[-1] for p in pyr]
+    mode = O.GRIDSAMPLE if widths[-1] >= 2 else O.EXACT          # grid_sample needs every level >= 2 wide
+    name = "gridsample" if mode == O.GRIDSAMPLE else "exact"
+    t1, t2 = dev(f1).requires_grad_(True), dev(f2).requires_grad_(True)
+    blk = R.CorrBlock1DHip(t1, t2, num_levels=L, radius=r, coord_mode=name)
+    for i in range(L):
+        assert rel(blk.dense_level(i), pyr[i]) < TOL32
+    out = blk(dev(coords))
+    assert rel(out, O.lookup(pyr, coords, r, mode)) < TOL32
+    (out * dev(G)).sum().backward()
+    d1, d2 = O.corr_volume_bwd(O.pool_pyramid_bwd(O.lookup_bwd(coords, G, widths, r, mode)), f1, f2)
+    assert rel(t1.grad, d1) < TOL32 and rel(t2.grad, d2) < TOL32
+    if r <= 6:
+        alt = R.AltCorrBlock1DHip(dev(f1), dev(f2), num_levels=L, radius=r, coord_mode=name)(dev(coords))
+        assert rel(alt, O.lookup(pyr, coords, r, mode)) < TOL32
+    h1, h2 = dev(f1, torch.bfloat16), dev(f2, torch.bfloat16)
+    ref16 = O.lookup_exact(O.pool_pyramid(O.corr_volume(h1.float().cpu().numpy(), h2.float().cpu().numpy()), L,
+                                          round_to=O.round_bf16), coords, r)
+    assert rel(R.CorrBlock1DHip(h1, h2, num_levels=L, radius=r)(dev(coords)), ref16) < TOL16[torch.bfloat16]
+
+
 # ------------------------------------------------------------------ fused lookup + convc1 (SURVEY 8f rank 1)
 @pytest.mark.parametrize("case", CONVC1_CASES)
 @pytest.mark.parametrize("kind", KINDS)
