@@ -228,6 +228,51 @@ int rc_alt_fwd(const void* f1t, const void* f2t, const rc_alt_layout* lay, int i
                const float* coords, int coords_channels, float* out, int radius,
                int coord_mode, void* stream);
 
+/*
+ * SURVEY.md section 8(f) rank 3 -- the pointwise arithmetic of ConvGRU.forward (core/update.py:23-32).
+ * The three convolutions stay with the caller; the library does what surrounds them, reading every
+ * operand once:
+ *     rc_gru_gate_r:  rh = sigmoid(convr_out + cr) * h                                (update.py:28-29)
+ *     rc_gru_update:  h_out = (1 - z) * h + z * q,  z = sigmoid(convz_out + cz),
+ *                                                   q = tanh(convq_out + cq)          (update.py:27,29,31)
+ * All tensors are [N, C, H, W] of `dtype` with per_batch = C*H*W elements per image.  convX_out, h, h_out
+ * are contiguous; cz/cr/cq may be channel slices of a wider tensor (the `.split` views of
+ * core/raft_stereo.py:88) and rh may be a channel slice of the buffer the next convolution reads
+ * ([r*h, x], update.py:29): those take the distance between images in elements.  h_out may alias h.
+ * 16-bit types round after every elementary operation, as the chain of torch ops under autocast does.
+ * The _bwd twins are the adjoints (gates recomputed from the saved pre-activations):
+ *     rc_gru_update_bwd: grad_z_pre (for convz_out and cz), grad_q_pre (for convq_out and cq), grad_h = g (1-z)
+ *     rc_gru_gate_r_bwd: grad_r_pre (for convr_out and cr), grad_h (+)= grad_rh * r  (accumulate_grad_h != 0
+ *                        adds to what grad_h holds: h is used by both kernels)
+ */
+int rc_gru_gate_r(const void* convr_out, const void* cr, int64_t cr_batch_stride, const void* h,
+                  void* rh, int64_t rh_batch_stride, int64_t N, int64_t per_batch, int dtype,
+                  void* stream);
+int rc_gru_update(const void* convz_out, const void* cz, int64_t cz_batch_stride,
+                  const void* convq_out, const void* cq, int64_t cq_batch_stride, const void* h,
+                  void* h_out, int64_t N, int64_t per_batch, int dtype, void* stream);
+int rc_gru_update_bwd(const void* convz_out, const void* cz, int64_t cz_batch_stride,
+                      const void* convq_out, const void* cq, int64_t cq_batch_stride, const void* h,
+                      const void* grad_h_out, void* grad_z_pre, void* grad_q_pre, void* grad_h,
+                      int64_t N, int64_t per_batch, int dtype, void* stream);
+int rc_gru_gate_r_bwd(const void* convr_out, const void* cr, int64_t cr_batch_stride, const void* h,
+                      const void* grad_rh, int64_t grad_rh_batch_stride, void* grad_r_pre,
+                      void* grad_h, int accumulate_grad_h, int64_t N, int64_t per_batch, int dtype,
+                      void* stream);
+
+/*
+ * SURVEY.md section 8(f) rank 4 -- convex upsampling, RAFTStereo.upsample_flow (core/raft_stereo.py:55-67):
+ *     out[n, c, f*h + fy, f*w + fx] = sum_k softmax_k(mask[n, k, fy, fx, h, w]) * f * flow[n, c, h + k/3 - 1, w + k%3 - 1]
+ * (zeros outside the image, F.unfold padding=1).  flow: float [N, >=channels, H, W], the first `channels`
+ * (1 or 2; the caller keeps only channel 0, raft_stereo.py:134) planes of each image are used and images are
+ * flow_batch_stride elements apart; mask: [N, 9*f*f, H, W] of mask_dtype, contiguous; out: float
+ * [N, channels, f*H, f*W].  factor f in {1, 2, 4, 8} (= 2**n_downsample).  The softmax is evaluated in fp32 and
+ * rounded to mask_dtype (what torch.softmax on the autocast mask returns); products and sum are fp32.
+ */
+int rc_upsample_flow_fwd(const float* flow, int64_t flow_batch_stride, const void* mask, float* out,
+                         int64_t N, int channels, int64_t H, int64_t W, int factor, int mask_dtype,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

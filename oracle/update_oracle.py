@@ -1,0 +1,100 @@
+"""CPU oracle for the pointwise work of a GRU iteration (numpy, float32): ConvGRU gate arithmetic and
+the convex upsampling of the disparity field (SURVEY.md section 8 f, ranks 3 and 4).
+
+TEST INFRASTRUCTURE ONLY.  Nothing in the product package imports this file; only `tests/`,
+`__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py` may.
+
+Every function restates one piece of the reference and cites it (paths are relative to the upstream
+tree, which is NOT shipped):
+
+  gru_gate_r        core/update.py:28-29      r = sigmoid(convr(hx) + cr);  r * h
+  gru_update        core/update.py:27,29,31   z, q, h = (1-z)*h + z*q
+  gru_update_bwd,
+  gru_gate_r_bwd    autograd of the same lines
+  upsample_flow     core/raft_stereo.py:55-67 softmax over 9, unfold(factor*flow, 3x3, padding=1), sum, permute
+
+Parity pin: tests/test_oracle_golden.py checks these against vectors captured from the reference's own
+Python (tests/golden/make_golden_update.py ran `core.update.ConvGRU` and `RAFTStereo.upsample_flow` on
+CPU in the build container and recorded the convolution outputs next to the results).  The reference
+has no tests or fixtures of its own for these lines.
+"""
+import numpy as np
+
+F32 = np.float32
+
+
+def _rounder(round_to):
+    """Every torch op on a 16-bit tensor evaluates in fp32 and rounds its result to the tensor type;
+    `round_to` (None, np.float16, or a callable for bf16) re-applies that rounding after each step."""
+    if round_to is None:
+        return lambda x: np.asarray(x, dtype=F32)
+    if callable(round_to) and not isinstance(round_to, type):
+        return lambda x: np.asarray(round_to(np.asarray(x, dtype=F32)), dtype=F32)
+    return lambda x: np.asarray(x, dtype=F32).astype(round_to).astype(F32)
+
+
+def _sigmoid(x):
+    x = np.asarray(x, dtype=np.float64)
+    return (1.0 / (1.0 + np.exp(-x))).astype(F32)
+
+
+def _tanh(x):
+    return np.tanh(np.asarray(x, dtype=np.float64)).astype(F32)
+
+
+def gru_gate_r(convr_out, cr, h, round_to=None):
+    """r * h with r = sigmoid(convr_out + cr)   (core/update.py:28-29)."""
+    rd = _rounder(round_to)
+    r = rd(_sigmoid(rd(rd(convr_out) + rd(cr))))
+    return rd(r * rd(h))
+
+
+def gru_update(convz_out, cz, convq_out, cq, h, round_to=None):
+    """h' = (1-z)*h + z*q,  z = sigmoid(convz_out + cz),  q = tanh(convq_out + cq)   (core/update.py:27,29,31)."""
+    rd = _rounder(round_to)
+    z = rd(_sigmoid(rd(rd(convz_out) + rd(cz))))
+    q = rd(_tanh(rd(rd(convq_out) + rd(cq))))
+    return rd(rd(rd(F32(1) - z) * rd(h)) + rd(z * q))
+
+
+def gru_update_bwd(convz_out, cz, convq_out, cq, h, grad_out):
+    """Adjoint of gru_update: (d z_pre, d q_pre, d h)."""
+    z = _sigmoid(np.asarray(convz_out, F32) + np.asarray(cz, F32)).astype(np.float64)
+    q = _tanh(np.asarray(convq_out, F32) + np.asarray(cq, F32)).astype(np.float64)
+    g, h = np.asarray(grad_out, np.float64), np.asarray(h, np.float64)
+    return ((g * (q - h) * z * (1 - z)).astype(F32), (g * z * (1 - q * q)).astype(F32), (g * (1 - z)).astype(F32))
+
+
+def gru_gate_r_bwd(convr_out, cr, h, grad_rh):
+    """Adjoint of gru_gate_r: (d r_pre, d h)."""
+    r = _sigmoid(np.asarray(convr_out, F32) + np.asarray(cr, F32)).astype(np.float64)
+    g, h = np.asarray(grad_rh, np.float64), np.asarray(h, np.float64)
+    return (g * h * r * (1 - r)).astype(F32), (g * r).astype(F32)
+
+
+def upsample_flow(flow, mask, factor, round_to=None):
+    """[N,D,H,W] flow + [N,9*f*f,H,W] mask logits -> [N,D,f*H,f*W]   (core/raft_stereo.py:55-67).
+
+    mask.view(N,1,9,f,f,H,W) -> softmax over the 9 -> sum_k mask_k * unfold(f*flow)_k -> permute(0,1,4,2,5,3):
+    out[n,d,f*h+fy,f*w+fx].  `round_to` is the mask's storage type: torch.softmax returns that type."""
+    rd = _rounder(round_to)
+    flow = np.asarray(flow, dtype=F32)
+    N, D, H, W = flow.shape
+    f = factor
+    m = rd(mask).reshape(N, 9, f, f, H, W).astype(np.float64)
+    m = m - m.max(axis=1, keepdims=True)
+    e = np.exp(m)
+    p = rd((e / e.sum(axis=1, keepdims=True)).astype(F32))                  # [N,9,f,f,H,W]
+    pad = np.zeros((N, D, H + 2, W + 2), dtype=F32)
+    pad[:, :, 1:-1, 1:-1] = F32(f) * flow
+    out = np.zeros((N, D, f, f, H, W), dtype=F32)
+    for k in range(9):                                                      # unfold order: k = ky*3 + kx
+        ky, kx = divmod(k, 3)
+        nb = pad[:, :, ky:ky + H, kx:kx + W]                                # [N,D,H,W]
+        out += p[:, None, k] * nb[:, :, None, None]
+    return np.ascontiguousarray(out.transpose(0, 1, 4, 2, 5, 3)).reshape(N, D, f * H, f * W)
+
+
+def rel_to_max(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))

@@ -1,0 +1,472 @@
+// Pointwise work of one GRU iteration that surrounds the correlation lookup (SURVEY.md section 8 f,
+// ranks 3 and 4): the ConvGRU gate arithmetic and the convex upsampling of the disparity field.
+//
+// Replaces, in the reference:
+//   rc_gru_gate_r / rc_gru_update     core/update.py:27-31   (the sigmoid / tanh / blend around the
+//                                     three convolutions of ConvGRU.forward; the convolutions stay
+//                                     with the caller)
+//   rc_upsample_flow_fwd              core/raft_stereo.py:55-67  (softmax over the 9 neighbours,
+//                                     unfold of factor*flow, weighted sum, permute)
+// All three are streaming kernels (HBM bound): every operand is read once with the widest load the
+// alignment allows and every result is written once.
+#include "rc_common.h"
+
+#include <math.h>
+
+namespace {
+
+constexpr int PW_THREADS = 256;
+
+// ------------------------------------------------------------------------------------------ GRU
+// What a chain of torch ops on 16-bit tensors computes: every op evaluates in fp32 and rounds its
+// result to the tensor type.  rnd<T>() marks each of those roundings (identity for float).
+template <typename T> __device__ __forceinline__ float rnd(float v) { return rc_round_as<T>(v); }
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <typename T, int VEC> struct pw_vec {
+  typedef T type __attribute__((ext_vector_type(VEC)));
+};
+template <typename T> struct pw_vec<T, 1> {
+  struct type {
+    T v;
+    __device__ __forceinline__ T& operator[](int) { return v; }
+    __device__ __forceinline__ const T& operator[](int) const { return v; }
+  };
+};
+
+template <typename T, int VEC>
+__device__ __forceinline__ typename pw_vec<T, VEC>::type pw_load(const T* p) {
+  return *reinterpret_cast<const typename pw_vec<T, VEC>::type*>(p);
+}
+
+// r*h of core/update.py:28-29:  r = sigmoid(convr(hx) + cr);  out = r * h
+template <typename T, int VEC>
+__global__ __launch_bounds__(PW_THREADS) void gru_gate_r_kernel(const T* __restrict__ convr, const T* __restrict__ cr,
+                                                                int64_t cr_bs, const T* __restrict__ h,
+                                                                T* __restrict__ rh, int64_t rh_bs, int64_t per_batch,
+                                                                int64_t total) {
+  const int64_t e = ((int64_t)blockIdx.x * PW_THREADS + threadIdx.x) * VEC;
+  if (e >= total) return;
+  const int64_t b = e / per_batch, i = e - b * per_batch;
+  const auto a = pw_load<T, VEC>(convr + e);
+  const auto c = pw_load<T, VEC>(cr + b * cr_bs + i);
+  const auto hv = pw_load<T, VEC>(h + e);
+  typename pw_vec<T, VEC>::type o;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    const float s = rnd<T>(rc_to_float(a[j]) + rc_to_float(c[j]));
+    const float r = rnd<T>(sigmoidf_(s));
+    o[j] = rc_from_float<T>(r * rc_to_float(hv[j]));
+  }
+  *reinterpret_cast<typename pw_vec<T, VEC>::type*>(rh + b * rh_bs + i) = o;
+}
+
+// core/update.py:27,29,31:  z = sigmoid(convz(hx) + cz);  q = tanh(convq([r*h, x]) + cq);  h = (1-z)*h + z*q
+template <typename T, int VEC>
+__global__ __launch_bounds__(PW_THREADS) void gru_update_kernel(const T* __restrict__ convz, const T* __restrict__ cz,
+                                                                int64_t cz_bs, const T* __restrict__ convq,
+                                                                const T* __restrict__ cq, int64_t cq_bs,
+                                                                const T* h, T* h_out, int64_t per_batch,
+                                                                int64_t total) {
+  const int64_t e = ((int64_t)blockIdx.x * PW_THREADS + threadIdx.x) * VEC;
+  if (e >= total) return;
+  const int64_t b = e / per_batch, i = e - b * per_batch;
+  const auto az = pw_load<T, VEC>(convz + e);
+  const auto bz = pw_load<T, VEC>(cz + b * cz_bs + i);
+  const auto aq = pw_load<T, VEC>(convq + e);
+  const auto bq = pw_load<T, VEC>(cq + b * cq_bs + i);
+  const auto hv = pw_load<T, VEC>(h + e);
+  typename pw_vec<T, VEC>::type o;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    const float z = rnd<T>(sigmoidf_(rnd<T>(rc_to_float(az[j]) + rc_to_float(bz[j]))));
+    const float q = rnd<T>(tanhf(rnd<T>(rc_to_float(aq[j]) + rc_to_float(bq[j]))));
+    const float keep = rnd<T>(rnd<T>(1.0f - z) * rc_to_float(hv[j]));
+    const float take = rnd<T>(z * q);
+    o[j] = rc_from_float<T>(keep + take);
+  }
+  *reinterpret_cast<typename pw_vec<T, VEC>::type*>(h_out + e) = o;
+}
+
+// Adjoint of gru_update_kernel (autograd of core/update.py:27,29,31), gates recomputed from the saved
+// pre-activations:  dz_pre = g (q - h) z (1-z),  dq_pre = g z (1 - q^2),  dh = g (1-z)
+template <typename T, int VEC>
+__global__ __launch_bounds__(PW_THREADS) void gru_update_bwd_kernel(
+    const T* __restrict__ convz, const T* __restrict__ cz, int64_t cz_bs, const T* __restrict__ convq,
+    const T* __restrict__ cq, int64_t cq_bs, const T* __restrict__ h, const T* __restrict__ gout,
+    T* __restrict__ dzpre, T* __restrict__ dqpre, T* __restrict__ dh, int64_t per_batch, int64_t total) {
+  const int64_t e = ((int64_t)blockIdx.x * PW_THREADS + threadIdx.x) * VEC;
+  if (e >= total) return;
+  const int64_t b = e / per_batch, i = e - b * per_batch;
+  const auto az = pw_load<T, VEC>(convz + e);
+  const auto bz = pw_load<T, VEC>(cz + b * cz_bs + i);
+  const auto aq = pw_load<T, VEC>(convq + e);
+  const auto bq = pw_load<T, VEC>(cq + b * cq_bs + i);
+  const auto hv = pw_load<T, VEC>(h + e);
+  const auto gv = pw_load<T, VEC>(gout + e);
+  typename pw_vec<T, VEC>::type oz, oq, oh;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    const float z = rnd<T>(sigmoidf_(rnd<T>(rc_to_float(az[j]) + rc_to_float(bz[j]))));
+    const float q = rnd<T>(tanhf(rnd<T>(rc_to_float(aq[j]) + rc_to_float(bq[j]))));
+    const float g = rc_to_float(gv[j]), hh = rc_to_float(hv[j]);
+    oz[j] = rc_from_float<T>(g * (q - hh) * z * (1.0f - z));
+    oq[j] = rc_from_float<T>(g * z * (1.0f - q * q));
+    oh[j] = rc_from_float<T>(g * (1.0f - z));
+  }
+  *reinterpret_cast<typename pw_vec<T, VEC>::type*>(dzpre + e) = oz;
+  *reinterpret_cast<typename pw_vec<T, VEC>::type*>(dqpre + e) = oq;
+  *reinterpret_cast<typename pw_vec<T, VEC>::type*>(dh + e) = oh;
+}
+
+// Adjoint of gru_gate_r_kernel:  dr_pre = g h r (1-r);  dh (+)= g r   (dh_accum != 0: added to what dh holds,
+// which is how the two uses of h in core/update.py:29,31 meet)
+template <typename T, int VEC>
+__global__ __launch_bounds__(PW_THREADS) void gru_gate_r_bwd_kernel(const T* __restrict__ convr,
+                                                                    const T* __restrict__ cr, int64_t cr_bs,
+                                                                    const T* __restrict__ h, const T* __restrict__ grh,
+                                                                    int64_t grh_bs, T* __restrict__ drpre, T* dh,
+                                                                    int dh_accum, int64_t per_batch, int64_t total) {
+  const int64_t e = ((int64_t)blockIdx.x * PW_THREADS + threadIdx.x) * VEC;
+  if (e >= total) return;
+  const int64_t b = e / per_batch, i = e - b * per_batch;
+  const auto a = pw_load<T, VEC>(convr + e);
+  const auto c = pw_load<T, VEC>(cr + b * cr_bs + i);
+  const auto hv = pw_load<T, VEC>(h + e);
+  const auto gv = pw_load<T, VEC>(grh + b * grh_bs + i);
+  typename pw_vec<T, VEC>::type prev;
+  if (dh_accum) prev = pw_load<T, VEC>(dh + e);
+  typename pw_vec<T, VEC>::type orr, oh;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    const float r = rnd<T>(sigmoidf_(rnd<T>(rc_to_float(a[j]) + rc_to_float(c[j]))));
+    const float g = rc_to_float(gv[j]);
+    orr[j] = rc_from_float<T>(g * rc_to_float(hv[j]) * r * (1.0f - r));
+    const float d = g * r;
+    oh[j] = rc_from_float<T>(dh_accum ? rc_to_float(prev[j]) + d : d);
+  }
+  *reinterpret_cast<typename pw_vec<T, VEC>::type*>(drpre + e) = orr;
+  *reinterpret_cast<typename pw_vec<T, VEC>::type*>(dh + e) = oh;
+}
+
+inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+inline int pw_blocks(int64_t total, int vec, unsigned* blocks) {
+  const int64_t n = (total / vec + PW_THREADS - 1) / PW_THREADS;
+  RC_REQUIRE(n < (1ll << 31), RC_EINVAL, "too many elements");
+  *blocks = (unsigned)n;
+  return RC_OK;
+}
+
+inline int pw_check(int64_t N, int64_t per_batch, int dtype) {
+  RC_REQUIRE(N > 0 && per_batch > 0 && N < (1ll << 31) && per_batch < (1ll << 40), RC_EINVAL,
+             "bad sizes N=%lld per_batch=%lld", (long long)N, (long long)per_batch);
+  RC_REQUIRE(dtype == RC_F32 || dtype == RC_F16 || dtype == RC_BF16, RC_EUNSUPPORTED, "unknown dtype %d", dtype);
+  return RC_OK;
+}
+
+template <typename T>
+int launch_gate_r(const void* convr, const void* cr, int64_t cr_bs, const void* h, void* rh, int64_t rh_bs,
+                  int64_t N, int64_t per_batch, hipStream_t st) {
+  constexpr int V = 16 / (int)sizeof(T);
+  const int64_t total = N * per_batch;
+  const bool vec = per_batch % V == 0 && cr_bs % V == 0 && rh_bs % V == 0 && aligned16(convr) && aligned16(cr) &&
+                   aligned16(h) && aligned16(rh);
+  unsigned blocks;
+  int rc = pw_blocks(total, vec ? V : 1, &blocks);
+  if (rc) return rc;
+  if (vec)
+    hipLaunchKernelGGL((gru_gate_r_kernel<T, V>), dim3(blocks), dim3(PW_THREADS), 0, st, (const T*)convr,
+                       (const T*)cr, cr_bs, (const T*)h, (T*)rh, rh_bs, per_batch, total);
+  else
+    hipLaunchKernelGGL((gru_gate_r_kernel<T, 1>), dim3(blocks), dim3(PW_THREADS), 0, st, (const T*)convr,
+                       (const T*)cr, cr_bs, (const T*)h, (T*)rh, rh_bs, per_batch, total);
+  return rc_check_launch("rc_gru_gate_r");
+}
+
+template <typename T>
+int launch_update(const void* convz, const void* cz, int64_t cz_bs, const void* convq, const void* cq,
+                  int64_t cq_bs, const void* h, void* h_out, int64_t N, int64_t per_batch, hipStream_t st) {
+  constexpr int V = 16 / (int)sizeof(T);
+  const int64_t total = N * per_batch;
+  const bool vec = per_batch % V == 0 && cz_bs % V == 0 && cq_bs % V == 0 && aligned16(convz) && aligned16(cz) &&
+                   aligned16(convq) && aligned16(cq) && aligned16(h) && aligned16(h_out);
+  unsigned blocks;
+  int rc = pw_blocks(total, vec ? V : 1, &blocks);
+  if (rc) return rc;
+  if (vec)
+    hipLaunchKernelGGL((gru_update_kernel<T, V>), dim3(blocks), dim3(PW_THREADS), 0, st, (const T*)convz,
+                       (const T*)cz, cz_bs, (const T*)convq, (const T*)cq, cq_bs, (const T*)h, (T*)h_out, per_batch,
+                       total);
+  else
+    hipLaunchKernelGGL((gru_update_kernel<T, 1>), dim3(blocks), dim3(PW_THREADS), 0, st, (const T*)convz,
+                       (const T*)cz, cz_bs, (const T*)convq, (const T*)cq, cq_bs, (const T*)h, (T*)h_out, per_batch,
+                       total);
+  return rc_check_launch("rc_gru_update");
+}
+
+template <typename T>
+int launch_update_bwd(const void* convz, const void* cz, int64_t cz_bs, const void* convq, const void* cq,
+                      int64_t cq_bs, const void* h, const void* gout, void* dz, void* dq, void* dh, int64_t N,
+                      int64_t per_batch, hipStream_t st) {
+  constexpr int V = 16 / (int)sizeof(T);
+  const int64_t total = N * per_batch;
+  const bool vec = per_batch % V == 0 && cz_bs % V == 0 && cq_bs % V == 0 && aligned16(convz) && aligned16(cz) &&
+                   aligned16(convq) && aligned16(cq) && aligned16(h) && aligned16(gout) && aligned16(dz) &&
+                   aligned16(dq) && aligned16(dh);
+  unsigned blocks;
+  int rc = pw_blocks(total, vec ? V : 1, &blocks);
+  if (rc) return rc;
+  if (vec)
+    hipLaunchKernelGGL((gru_update_bwd_kernel<T, V>), dim3(blocks), dim3(PW_THREADS), 0, st, (const T*)convz,
+                       (const T*)cz, cz_bs, (const T*)convq, (const T*)cq, cq_bs, (const T*)h, (const T*)gout,
+                       (T*)dz, (T*)dq, (T*)dh, per_batch, total);
+  else
+    hipLaunchKernelGGL((gru_update_bwd_kernel<T, 1>), dim3(blocks), dim3(PW_THREADS), 0, st, (const T*)convz,
+                       (const T*)cz, cz_bs, (const T*)convq, (const T*)cq, cq_bs, (const T*)h, (const T*)gout,
+                       (T*)dz, (T*)dq, (T*)dh, per_batch, total);
+  return rc_check_launch("rc_gru_update_bwd");
+}
+
+template <typename T>
+int launch_gate_r_bwd(const void* convr, const void* cr, int64_t cr_bs, const void* h, const void* grh,
+                      int64_t grh_bs, void* dr, void* dh, int dh_accum, int64_t N, int64_t per_batch,
+                      hipStream_t st) {
+  constexpr int V = 16 / (int)sizeof(T);
+  const int64_t total = N * per_batch;
+  const bool vec = per_batch % V == 0 && cr_bs % V == 0 && grh_bs % V == 0 && aligned16(convr) && aligned16(cr) &&
+                   aligned16(h) && aligned16(grh) && aligned16(dr) && aligned16(dh);
+  unsigned blocks;
+  int rc = pw_blocks(total, vec ? V : 1, &blocks);
+  if (rc) return rc;
+  if (vec)
+    hipLaunchKernelGGL((gru_gate_r_bwd_kernel<T, V>), dim3(blocks), dim3(PW_THREADS), 0, st, (const T*)convr,
+                       (const T*)cr, cr_bs, (const T*)h, (const T*)grh, grh_bs, (T*)dr, (T*)dh, dh_accum, per_batch,
+                       total);
+  else
+    hipLaunchKernelGGL((gru_gate_r_bwd_kernel<T, 1>), dim3(blocks), dim3(PW_THREADS), 0, st, (const T*)convr,
+                       (const T*)cr, cr_bs, (const T*)h, (const T*)grh, grh_bs, (T*)dr, (T*)dh, dh_accum, per_batch,
+                       total);
+  return rc_check_launch("rc_gru_gate_r_bwd");
+}
+
+// ------------------------------------------------------------------------------------- upsampling
+// A wave owns 64 consecutive low-resolution pixels of one row and ONE of the F output rows they
+// expand into (fy); the F waves of a pixel chunk sit next to each other in the grid.  Per group of
+// G = min(F,4) output columns (fx) the lane loads its 9 G mask logits (every load of the wave is one
+// contiguous run of a mask plane), normalises them and writes G consecutive output pixels per flow
+// channel as one 8/16-byte store: the wave's store is one contiguous run of an output row.
+// MT is the mask type: softmax evaluates in fp32 and rounds to MT, as torch.softmax on an MT tensor
+// does (core/raft_stereo.py:60; the mask is fp16 under autocast), the products and the sum are fp32.
+template <int G> struct up_vec;
+template <> struct up_vec<1> { typedef float type; };
+template <> struct up_vec<2> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct up_vec<4> { typedef float type __attribute__((ext_vector_type(4))); };
+
+__device__ __forceinline__ int64_t up_uniform(int64_t v) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uint64_t)v);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+template <typename MT, int F, int C>
+__global__ __launch_bounds__(PW_THREADS) void upsample_kernel(const float* __restrict__ flow, int64_t flow_bs,
+                                                              const MT* __restrict__ mask, float* __restrict__ out,
+                                                              int H, int W, int chunks_per_row, int n_items) {
+  constexpr int G = F < 4 ? F : 4;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int item = blockIdx.x * (PW_THREADS / 64) + wave;  // ((n*H + h)*chunks + chunk)*F + fy, wave-uniform
+  if (item >= n_items) return;
+  const int fy = item % F;
+  const int t = item / F;
+  const int nh = t / chunks_per_row;
+  const int c0 = (t - nh * chunks_per_row) * 64;
+  const int n = nh / H, h = nh - n * H;
+  const int w = c0 + lane;
+  if (w >= W) return;
+  const int64_t HW = (int64_t)H * W;
+
+  // factor * flow at the 9 neighbours (F.unfold(factor*flow, [3,3], padding=1): zeros outside)
+  float v[C][9];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int hh = h + ky - 1;
+    const bool rok = (unsigned)hh < (unsigned)H;  // wave-uniform
+    const float* frow = flow + up_uniform((int64_t)n * flow_bs + (int64_t)(rok ? hh : h) * W);
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ww = w + kx - 1;
+      const bool ok = rok && (unsigned)ww < (unsigned)W;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float f = (frow + (int64_t)c * HW)[ok ? ww : w];
+        v[c][ky * 3 + kx] = ok ? (float)F * f : 0.f;
+      }
+    }
+  }
+
+  // mask[n, k, fy, fx, h, w]: plane (k*F + fy)*F + fx of image n
+  const MT* mrow = mask + up_uniform(((int64_t)n * 9 * F * F + (int64_t)fy * F) * HW + (int64_t)h * W + c0);
+  float* orow = out + up_uniform((((int64_t)n * C * H + h) * F + fy) * (int64_t)F * W + (int64_t)F * c0);
+  const uint32_t HWu = (uint32_t)HW;
+#pragma unroll
+  for (int g0 = 0; g0 < F; g0 += G) {
+    float m[9][G];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+      for (int j = 0; j < G; ++j) m[k][j] = rc_to_float(mrow[(uint32_t)(k * F * F + g0 + j) * HWu + (uint32_t)lane]);
+    float res[C][G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      float mx = m[0][j];
+#pragma unroll
+      for (int k = 1; k < 9; ++k) mx = fmaxf(mx, m[k][j]);
+      float e[9], s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        e[k] = expf(m[k][j] - mx);
+        s += e[k];
+      }
+#pragma unroll
+      for (int c = 0; c < C; ++c) res[c][j] = 0.f;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const float p = rc_round_as<MT>(e[k] / s);
+#pragma unroll
+        for (int c = 0; c < C; ++c) res[c][j] += p * v[c][k];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      typename up_vec<G>::type o;
+      if constexpr (G == 1) {
+        o = res[c][0];
+      } else {
+#pragma unroll
+        for (int j = 0; j < G; ++j) o[j] = res[c][j];
+      }
+      float* dst = orow + up_uniform((int64_t)c * H * F * F * W) + (uint32_t)(lane * F + g0);
+      *reinterpret_cast<typename up_vec<G>::type*>(dst) = o;
+    }
+  }
+}
+
+template <typename MT, int F, int C>
+int launch_upsample(const float* flow, int64_t flow_bs, const void* mask, float* out, int64_t N, int64_t H,
+                    int64_t W, hipStream_t st) {
+  const int chunks = (int)((W + 63) / 64);
+  const int64_t items = N * H * chunks * F;
+  RC_REQUIRE(items < (1ll << 31), RC_EINVAL, "too many pixels");
+  const int blocks = (int)((items + PW_THREADS / 64 - 1) / (PW_THREADS / 64));
+  hipLaunchKernelGGL((upsample_kernel<MT, F, C>), dim3(blocks), dim3(PW_THREADS), 0, st, flow, flow_bs,
+                     (const MT*)mask, out, (int)H, (int)W, chunks, (int)items);
+  return rc_check_launch("rc_upsample_flow_fwd");
+}
+
+template <typename MT, int F>
+int launch_upsample_c(const float* flow, int64_t flow_bs, const void* mask, float* out, int64_t N, int C,
+                      int64_t H, int64_t W, hipStream_t st) {
+  return C == 1 ? launch_upsample<MT, F, 1>(flow, flow_bs, mask, out, N, H, W, st)
+                : launch_upsample<MT, F, 2>(flow, flow_bs, mask, out, N, H, W, st);
+}
+
+template <typename MT>
+int launch_upsample_f(const float* flow, int64_t flow_bs, const void* mask, float* out, int64_t N, int C,
+                      int64_t H, int64_t W, int factor, hipStream_t st) {
+  switch (factor) {
+    case 1: return launch_upsample_c<MT, 1>(flow, flow_bs, mask, out, N, C, H, W, st);
+    case 2: return launch_upsample_c<MT, 2>(flow, flow_bs, mask, out, N, C, H, W, st);
+    case 4: return launch_upsample_c<MT, 4>(flow, flow_bs, mask, out, N, C, H, W, st);
+    case 8: return launch_upsample_c<MT, 8>(flow, flow_bs, mask, out, N, C, H, W, st);
+  }
+  rc_set_error("upsampling factor %d is not one of 1, 2, 4, 8", factor);
+  return RC_EUNSUPPORTED;
+}
+
+}  // namespace
+
+#define RC_PW_DISPATCH(dtype, CALL)                           \
+  switch (dtype) {                                            \
+    case RC_F32: { using T = float; return CALL; }            \
+    case RC_F16: { using T = rc_half; return CALL; }          \
+    case RC_BF16: { using T = rc_bf16; return CALL; }         \
+  }                                                           \
+  return RC_EUNSUPPORTED;
+
+extern "C" int rc_gru_gate_r(const void* convr_out, const void* cr, int64_t cr_batch_stride, const void* h,
+                             void* rh, int64_t rh_batch_stride, int64_t N, int64_t per_batch, int dtype,
+                             void* stream) {
+  RC_REQUIRE(convr_out && cr && h && rh, RC_EINVAL, "null pointer argument");
+  int rc = pw_check(N, per_batch, dtype);
+  if (rc) return rc;
+  RC_REQUIRE(cr_batch_stride >= per_batch && rh_batch_stride >= per_batch, RC_EINVAL,
+             "a batch stride is shorter than one image (%lld)", (long long)per_batch);
+  hipStream_t st = (hipStream_t)stream;
+  RC_PW_DISPATCH(dtype, (launch_gate_r<T>(convr_out, cr, cr_batch_stride, h, rh, rh_batch_stride, N, per_batch, st)))
+}
+
+extern "C" int rc_gru_update(const void* convz_out, const void* cz, int64_t cz_batch_stride, const void* convq_out,
+                             const void* cq, int64_t cq_batch_stride, const void* h, void* h_out, int64_t N,
+                             int64_t per_batch, int dtype, void* stream) {
+  RC_REQUIRE(convz_out && cz && convq_out && cq && h && h_out, RC_EINVAL, "null pointer argument");
+  int rc = pw_check(N, per_batch, dtype);
+  if (rc) return rc;
+  RC_REQUIRE(cz_batch_stride >= per_batch && cq_batch_stride >= per_batch, RC_EINVAL,
+             "a batch stride is shorter than one image (%lld)", (long long)per_batch);
+  hipStream_t st = (hipStream_t)stream;
+  RC_PW_DISPATCH(dtype, (launch_update<T>(convz_out, cz, cz_batch_stride, convq_out, cq, cq_batch_stride, h, h_out,
+                                          N, per_batch, st)))
+}
+
+extern "C" int rc_gru_update_bwd(const void* convz_out, const void* cz, int64_t cz_batch_stride,
+                                 const void* convq_out, const void* cq, int64_t cq_batch_stride, const void* h,
+                                 const void* grad_h_out, void* grad_z_pre, void* grad_q_pre, void* grad_h, int64_t N,
+                                 int64_t per_batch, int dtype, void* stream) {
+  RC_REQUIRE(convz_out && cz && convq_out && cq && h && grad_h_out && grad_z_pre && grad_q_pre && grad_h, RC_EINVAL,
+             "null pointer argument");
+  int rc = pw_check(N, per_batch, dtype);
+  if (rc) return rc;
+  RC_REQUIRE(cz_batch_stride >= per_batch && cq_batch_stride >= per_batch, RC_EINVAL,
+             "a batch stride is shorter than one image (%lld)", (long long)per_batch);
+  hipStream_t st = (hipStream_t)stream;
+  RC_PW_DISPATCH(dtype, (launch_update_bwd<T>(convz_out, cz, cz_batch_stride, convq_out, cq, cq_batch_stride, h,
+                                              grad_h_out, grad_z_pre, grad_q_pre, grad_h, N, per_batch, st)))
+}
+
+extern "C" int rc_gru_gate_r_bwd(const void* convr_out, const void* cr, int64_t cr_batch_stride, const void* h,
+                                 const void* grad_rh, int64_t grad_rh_batch_stride, void* grad_r_pre, void* grad_h,
+                                 int accumulate_grad_h, int64_t N, int64_t per_batch, int dtype, void* stream) {
+  RC_REQUIRE(convr_out && cr && h && grad_rh && grad_r_pre && grad_h, RC_EINVAL, "null pointer argument");
+  int rc = pw_check(N, per_batch, dtype);
+  if (rc) return rc;
+  RC_REQUIRE(cr_batch_stride >= per_batch && grad_rh_batch_stride >= per_batch, RC_EINVAL,
+             "a batch stride is shorter than one image (%lld)", (long long)per_batch);
+  hipStream_t st = (hipStream_t)stream;
+  RC_PW_DISPATCH(dtype, (launch_gate_r_bwd<T>(convr_out, cr, cr_batch_stride, h, grad_rh, grad_rh_batch_stride,
+                                              grad_r_pre, grad_h, accumulate_grad_h, N, per_batch, st)))
+}
+
+extern "C" int rc_upsample_flow_fwd(const float* flow, int64_t flow_batch_stride, const void* mask, float* out,
+                                    int64_t N, int channels, int64_t H, int64_t W, int factor, int mask_dtype,
+                                    void* stream) {
+  RC_REQUIRE(flow && mask && out, RC_EINVAL, "null pointer argument");
+  RC_REQUIRE(N > 0 && H > 0 && W > 0, RC_EINVAL, "non-positive size N=%lld H=%lld W=%lld", (long long)N,
+             (long long)H, (long long)W);
+  RC_REQUIRE(channels == 1 || channels == 2, RC_EUNSUPPORTED, "channels must be 1 or 2 (got %d)", channels);
+  RC_REQUIRE(flow_batch_stride >= (int64_t)channels * H * W, RC_EINVAL, "flow batch stride shorter than %d planes",
+             channels);
+  RC_REQUIRE(factor >= 1 && (int64_t)9 * factor * factor * H * W < (1ll << 30), RC_EINVAL,
+             "one image's mask exceeds the 32-bit lane offset range");
+  RC_REQUIRE(((uintptr_t)out & 15) == 0, RC_EINVAL, "out must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  switch (mask_dtype) {
+    case RC_F32: return launch_upsample_f<float>(flow, flow_batch_stride, mask, out, N, channels, H, W, factor, st);
+    case RC_F16: return launch_upsample_f<rc_half>(flow, flow_batch_stride, mask, out, N, channels, H, W, factor, st);
+    case RC_BF16: return launch_upsample_f<rc_bf16>(flow, flow_batch_stride, mask, out, N, channels, H, W, factor, st);
+  }
+  rc_set_error("unknown mask dtype %d", mask_dtype);
+  return RC_EUNSUPPORTED;
+}

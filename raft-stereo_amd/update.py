@@ -1,0 +1,193 @@
+"""The pointwise work of a GRU iteration around the correlation lookup, backed by libraftcorr_hip.so
+(SURVEY.md section 8 f, ranks 3 and 4).
+
+    ConvGRUHip(hidden_dim, input_dim, kernel_size=3)      core/update.py:16-32  ConvGRU
+        .forward(h, cz, cr, cq, *x_list)                  same parameters (convz/convr/convq), same call
+    upsample_flow_hip(flow, mask, n_downsample)           core/raft_stereo.py:55-67  RAFTStereo.upsample_flow
+
+The three convolutions of the GRU are torch's (dense convolutions are outside this package's path); the
+sigmoid / tanh / blend arithmetic around them and the whole convex upsampling run in the HIP library.
+There is no CPU or eager fallback: tensors must live on a GPU.
+"""
+import torch
+import torch.nn as nn
+
+from raft_stereo_amd import _lib
+from raft_stereo_amd._lib import lib, check
+from raft_stereo_amd.corr import _DT, _stream, _on_device
+
+
+def _batch_view(t, like, what):
+    """`t` as (pointer, batch stride) of an [N,C,H,W] operand whose images are dense: either contiguous or
+    a channel slice of a wider contiguous tensor (the `.split(dim=1)` views of core/raft_stereo.py:88).
+    Anything else is copied."""
+    if t.shape != like.shape or t.dtype != like.dtype or t.device != like.device:
+        raise ValueError(f"{what} must match h: {tuple(like.shape)} {like.dtype} on {like.device}, "
+                         f"got {tuple(t.shape)} {t.dtype} on {t.device}")
+    N, C, H, W = t.shape
+    if t.stride()[1:] != (H * W, W, 1) or (N > 1 and t.stride(0) < C * H * W):
+        t = t.contiguous()
+    return t, (t.stride(0) if N > 1 else C * H * W)
+
+
+class _GateRFn(torch.autograd.Function):
+    """rh = sigmoid(convr_out + cr) * h (out of place; the differentiable route)."""
+
+    @staticmethod
+    def forward(ctx, convr_out, cr, h):
+        cr_t, cr_bs = _batch_view(cr, h, "cr")
+        out = torch.empty_like(h)
+        _gate_r_raw(convr_out, cr_t, cr_bs, h, out)
+        ctx.save_for_backward(convr_out, cr_t, h)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_rh):
+        convr_out, cr_t, h = ctx.saved_tensors
+        g, g_bs = _batch_view(grad_rh, h, "grad_rh")
+        N, per = h.shape[0], h[0].numel()
+        d_pre, d_h = torch.empty_like(h), torch.empty_like(h)
+        with _on_device(h.device):
+            check(lib.rc_gru_gate_r_bwd(convr_out.data_ptr(), cr_t.data_ptr(), cr_t.stride(0) if N > 1 else per,
+                                        h.data_ptr(), g.data_ptr(), g_bs, d_pre.data_ptr(), d_h.data_ptr(), 0,
+                                        N, per, _DT[h.dtype], _stream(h.device)), "rc_gru_gate_r_bwd")
+        return d_pre, d_pre, d_h
+
+
+def _gate_r_raw(convr_out, cr_t, cr_bs, h, dst):
+    N, per = h.shape[0], h[0].numel()
+    with _on_device(h.device):
+        check(lib.rc_gru_gate_r(convr_out.data_ptr(), cr_t.data_ptr(), cr_bs, h.data_ptr(), dst.data_ptr(),
+                                dst.stride(0) if N > 1 else per, N, per, _DT[h.dtype], _stream(h.device)),
+              "rc_gru_gate_r")
+
+
+class _UpdateFn(torch.autograd.Function):
+    """h_out = (1-z)*h + z*q with z = sigmoid(convz_out + cz), q = tanh(convq_out + cq)."""
+
+    @staticmethod
+    def forward(ctx, convz_out, cz, convq_out, cq, h):
+        cz_t, cz_bs = _batch_view(cz, h, "cz")
+        cq_t, cq_bs = _batch_view(cq, h, "cq")
+        N, per = h.shape[0], h[0].numel()
+        out = torch.empty_like(h)
+        with _on_device(h.device):
+            check(lib.rc_gru_update(convz_out.data_ptr(), cz_t.data_ptr(), cz_bs, convq_out.data_ptr(),
+                                    cq_t.data_ptr(), cq_bs, h.data_ptr(), out.data_ptr(), N, per, _DT[h.dtype],
+                                    _stream(h.device)), "rc_gru_update")
+        ctx.save_for_backward(convz_out, cz_t, convq_out, cq_t, h)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        convz_out, cz_t, convq_out, cq_t, h = ctx.saved_tensors
+        N, per = h.shape[0], h[0].numel()
+        g = grad_out.contiguous()
+        dz, dq, dh = torch.empty_like(h), torch.empty_like(h), torch.empty_like(h)
+        with _on_device(h.device):
+            check(lib.rc_gru_update_bwd(convz_out.data_ptr(), cz_t.data_ptr(), cz_t.stride(0) if N > 1 else per,
+                                        convq_out.data_ptr(), cq_t.data_ptr(), cq_t.stride(0) if N > 1 else per,
+                                        h.data_ptr(), g.data_ptr(), dz.data_ptr(), dq.data_ptr(), dh.data_ptr(),
+                                        N, per, _DT[h.dtype], _stream(h.device)), "rc_gru_update_bwd")
+        return dz, dz, dq, dq, dh
+
+
+def _check_gru_operand(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(f"raft_stereo_amd GRU kernels need GPU tensors (there is no CPU path): {what}")
+    if t.dtype not in _DT:
+        raise TypeError(f"unsupported dtype {t.dtype} for {what}")
+    if t.dim() != 4:
+        raise ValueError(f"{what} must be [N, C, H, W]")
+
+
+def gru_gate_r(convr_out, cr, h, out=None):
+    """`sigmoid(convr_out + cr) * h` (core/update.py:28-29).  `out`, if given (inference only), is an
+    [N,C,H,W] channel slice of a wider buffer: the first hidden_dim channels of `torch.cat([r*h, x], dim=1)`."""
+    for t, w in ((convr_out, "convr_out"), (cr, "cr"), (h, "h")):
+        _check_gru_operand(t, w)
+    convr_out, h = convr_out.contiguous(), h.contiguous()
+    if convr_out.shape != h.shape or convr_out.dtype != h.dtype:
+        raise ValueError("convr_out must match h")
+    if out is None:
+        return _GateRFn.apply(convr_out, cr, h)
+    if torch.is_grad_enabled() and (convr_out.requires_grad or cr.requires_grad or h.requires_grad):
+        raise RuntimeError("gru_gate_r(out=...) writes in place and is forward-only")
+    if out.shape != h.shape or out.dtype != h.dtype or out.stride()[1:] != h.stride()[1:] \
+            or (h.shape[0] > 1 and out.stride(0) < h[0].numel()):
+        raise ValueError("out must be an [N,C,H,W] tensor of h's type whose images are dense")
+    cr_t, cr_bs = _batch_view(cr.detach(), h, "cr")
+    _gate_r_raw(convr_out.detach(), cr_t, cr_bs, h.detach(), out)
+    return out
+
+
+def gru_update(convz_out, cz, convq_out, cq, h):
+    """`(1-z)*h + z*q` with `z = sigmoid(convz_out + cz)`, `q = tanh(convq_out + cq)` (core/update.py:27-31)."""
+    for t, w in ((convz_out, "convz_out"), (cz, "cz"), (convq_out, "convq_out"), (cq, "cq"), (h, "h")):
+        _check_gru_operand(t, w)
+    convz_out, convq_out, h = convz_out.contiguous(), convq_out.contiguous(), h.contiguous()
+    if convz_out.shape != h.shape or convq_out.shape != h.shape or convz_out.dtype != h.dtype \
+            or convq_out.dtype != h.dtype:
+        raise ValueError("convz_out and convq_out must match h")
+    return _UpdateFn.apply(convz_out, cz, convq_out, cq, h)
+
+
+class ConvGRUHip(nn.Module):
+    """Drop-in for the reference's ConvGRU (core/update.py:16-32): same constructor, same parameter names
+    (a reference state_dict loads as is), same `forward(h, cz, cr, cq, *x_list)`.  convz and convr read the
+    same input, so they run as ONE convolution with stacked weights; everything pointwise is two library
+    kernels instead of eleven torch ops."""
+
+    def __init__(self, hidden_dim, input_dim, kernel_size=3):
+        super().__init__()
+        self.hidden_dim = hidden_dim
+        self.convz = nn.Conv2d(hidden_dim + input_dim, hidden_dim, kernel_size, padding=kernel_size // 2)
+        self.convr = nn.Conv2d(hidden_dim + input_dim, hidden_dim, kernel_size, padding=kernel_size // 2)
+        self.convq = nn.Conv2d(hidden_dim + input_dim, hidden_dim, kernel_size, padding=kernel_size // 2)
+
+    def forward(self, h, cz, cr, cq, *x_list):
+        C = self.hidden_dim
+        hx = torch.cat([h, *x_list], dim=1)                                   # update.py:24-25
+        if torch.is_autocast_enabled():           # what autocast would hand the convolutions
+            hx = hx.to(torch.get_autocast_gpu_dtype())
+        dt = hx.dtype
+        zr = nn.functional.conv2d(hx, torch.cat([self.convz.weight, self.convr.weight], dim=0).to(dt),
+                                  torch.cat([self.convz.bias, self.convr.bias], dim=0).to(dt),
+                                  padding=self.convz.padding)
+        zc, rc = zr[:, :C].contiguous(), zr[:, C:].contiguous()
+        h, cz, cr, cq = h.to(dt).contiguous(), cz.to(dt), cr.to(dt), cq.to(dt)
+        if torch.is_grad_enabled() and (zr.requires_grad or h.requires_grad or cr.requires_grad):
+            rhx = torch.cat([gru_gate_r(rc, cr, h), hx[:, C:]], dim=1)       # [r*h, x]  update.py:28-29
+        else:
+            gru_gate_r(rc, cr, h, out=hx[:, :C])  # hx is this call's own copy and both convolutions have read it
+            rhx = hx
+        qc = self.convq(rhx)
+        return gru_update(zc, cz, qc.to(dt), cq, h)                           # update.py:27,29,31
+
+
+def upsample_flow_hip(flow, mask, n_downsample, channels=None):
+    """RAFTStereo.upsample_flow (core/raft_stereo.py:55-67): `[N, D, H, W]` flow and `[N, 9*f*f, H, W]` mask
+    logits -> `[N, D, f*H, f*W]` fp32, f = 2**n_downsample.  `channels` = 1 computes only the x component (all
+    that core/raft_stereo.py:134 keeps).  Forward only."""
+    if torch.is_grad_enabled() and (flow.requires_grad or mask.requires_grad):
+        raise RuntimeError("upsample_flow_hip is forward-only: call it under torch.no_grad()")
+    if not (flow.is_cuda and mask.is_cuda) or flow.device != mask.device:
+        raise RuntimeError("upsample_flow_hip needs GPU tensors on one device (there is no CPU path)")
+    if flow.dim() != 4 or mask.dim() != 4:
+        raise ValueError("flow must be [N, D, H, W] and mask [N, 9*f*f, H, W]")
+    f = 2 ** n_downsample
+    N, D, H, W = flow.shape
+    C = D if channels is None else channels
+    if C not in (1, 2) or C > D:
+        raise ValueError(f"channels must be 1 or 2 and at most D={D}")
+    if tuple(mask.shape) != (N, 9 * f * f, H, W):
+        raise ValueError(f"mask must be [{N}, {9 * f * f}, {H}, {W}], got {tuple(mask.shape)}")
+    if mask.dtype not in _DT:
+        raise TypeError(f"unsupported mask dtype {mask.dtype}")
+    flow = flow.detach().float().contiguous()
+    mask = mask.detach().contiguous()
+    with _on_device(flow.device):
+        out = torch.empty((N, C, f * H, f * W), dtype=torch.float32, device=flow.device)
+        check(lib.rc_upsample_flow_fwd(flow.data_ptr(), D * H * W, mask.data_ptr(), out.data_ptr(), N, C, H, W, f,
+                                       _DT[mask.dtype], _stream(flow.device)), "rc_upsample_flow_fwd")
+    return out

@@ -1,0 +1,269 @@
+"""GPU parity tests for the pointwise work of a GRU iteration (SURVEY.md section 8 f, ranks 3 and 4):
+ConvGRU gate arithmetic and convex upsampling, through the C-ABI library, against the golden vectors
+captured from the reference's ConvGRU / upsample_flow and against the CPU oracle.
+
+Bars (metric max|a-b| / max|ref|): fp32 1e-5 for the library's own arithmetic (checked on the
+reference's recorded convolution outputs); 1e-4 where torch's GPU convolutions are part of the
+comparison (ConvGRUHip end to end; the convolutions are not this package's); fp16 2e-3, bf16 1.6e-2
+against the oracle evaluated with the same per-operation rounding.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import update_oracle as U
+from conftest import GRU_CASES, UPSAMPLE_CASES
+
+pytestmark = pytest.mark.gpu
+
+TOL32 = 1e-5
+TOL_CONV = 1e-4
+TOL16 = {torch.float16: 2e-3, torch.bfloat16: 1.6e-2}
+
+
+@pytest.fixture(scope="module")
+def R():
+    import raft_stereo_amd
+    assert torch.cuda.is_available(), "these tests need a GPU"
+    return raft_stereo_amd
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return t.to(dtype) if dtype is not None else t
+
+
+def rel(a, b):
+    return U.rel_to_max(a.detach().float().cpu().numpy() if torch.is_tensor(a) else a, b)
+
+
+def _round(a, dtype):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dtype).float().numpy()
+
+
+def _rounder(dtype):
+    return lambda x: _round(np.asarray(x, dtype=np.float32), dtype)
+
+
+def _ctx_views(g, dtype=None):
+    """cz, cr, cq as the reference hands them over: split views of one tensor (core/raft_stereo.py:88)."""
+    ctx = dev(g["ctx"], dtype)
+    return ctx, ctx.split(split_size=int(g["C"]), dim=1)
+
+
+# ------------------------------------------------------------------ GRU kernels on the reference's conv outputs
+@pytest.mark.parametrize("case", GRU_CASES)
+def test_gru_kernels_fp32_match_reference(R, golden, case):
+    g = golden(case)
+    C = int(g["C"])
+    _, (cz, cr, cq) = _ctx_views(g)
+    assert not cz.is_contiguous() or g["ctx"].shape[0] == 1
+    h = dev(g["h"])
+    out = R.gru_update(dev(g["zc"]), cz, dev(g["qc"]), cq, h)
+    assert rel(out, g["h_out"]) < TOL32
+    rh = R.gru_gate_r(dev(g["rc"]), cr, h)
+    assert rel(rh, U.gru_gate_r(g["rc"], g["ctx"][:, C:2 * C], g["h"])) < TOL32
+    # the same product written into the first C channels of the next convolution's input buffer
+    xs = [dev(g[f"x{i}"]) for i in range(int(g["n_x"]))]
+    buf = torch.cat([torch.full_like(h, 7.0)] + xs, dim=1)
+    keep = buf[:, C:].clone()
+    R.gru_gate_r(dev(g["rc"]), cr, h, out=buf[:, :C])
+    assert torch.equal(buf[:, :C], rh) and torch.equal(buf[:, C:], keep)
+    qc = torch.nn.functional.conv2d(buf, dev(g["w_convq.weight"]), dev(g["w_convq.bias"]), padding=1)
+    assert rel(qc, g["qc"]) < TOL_CONV
+
+
+@pytest.mark.parametrize("case", GRU_CASES)
+def test_gru_kernels_backward_fp32_match_reference_autograd(R, golden, case):
+    g = golden(case)
+    C = int(g["C"])
+    ctx = dev(g["ctx"]).requires_grad_(True)
+    cz, cr, cq = ctx.split(split_size=C, dim=1)
+    zc, rc, qc, h = (dev(g[k]).requires_grad_(True) for k in ("zc", "rc", "qc", "h"))
+    R.gru_update(zc, cz, qc, cq, h).backward(dev(g["grad_out"]))
+    assert rel(zc.grad, g["d_zc"]) < TOL32
+    assert rel(qc.grad, g["d_qc"]) < TOL32
+    assert rel(ctx.grad[:, :C], g["d_ctx"][:, :C]) < TOL32
+    assert rel(ctx.grad[:, 2 * C:], g["d_ctx"][:, 2 * C:]) < TOL32
+    _, _, dh_u = U.gru_update_bwd(g["zc"], g["ctx"][:, :C], g["qc"], g["ctx"][:, 2 * C:], g["h"], g["grad_out"])
+    assert rel(h.grad, dh_u) < TOL32
+    # gate adjoint: d(r*h) is the input gradient of the reference's convq at its first C channels
+    d_rh = torch.nn.grad.conv2d_input((h.shape[0], g["w_convq.weight"].shape[1]) + tuple(h.shape[2:]),
+                                      torch.from_numpy(g["w_convq.weight"]), torch.from_numpy(g["d_qc"]),
+                                      padding=1)[:, :C].contiguous()
+    ctx.grad = None
+    h.grad = None
+    R.gru_gate_r(rc, cr, h).backward(d_rh.cuda())
+    assert rel(rc.grad, g["d_rc"]) < TOL32
+    assert rel(ctx.grad[:, C:2 * C], g["d_ctx"][:, C:2 * C]) < TOL32
+    _, dh_r = U.gru_gate_r_bwd(g["rc"], g["ctx"][:, C:2 * C], g["h"], d_rh.numpy())
+    assert rel(h.grad, dh_r) < TOL32
+
+
+def test_gate_r_bwd_accumulates_into_grad_h(R, golden):
+    """rc_gru_gate_r_bwd(accumulate_grad_h=1) adds to what grad_h holds (the C-ABI route for callers that
+    chain the two adjoints without autograd)."""
+    from raft_stereo_amd._lib import lib, check, RC_F32
+    g = golden(GRU_CASES[0])
+    C = int(g["C"])
+    rc, h = dev(g["rc"]), dev(g["h"])
+    cr = dev(g["ctx"][:, C:2 * C])
+    grh = torch.randn_like(h)
+    N, per = h.shape[0], h[0].numel()
+    d_pre, base = torch.empty_like(h), torch.randn_like(h)
+    acc = base.clone()
+    check(lib.rc_gru_gate_r_bwd(rc.data_ptr(), cr.data_ptr(), per, h.data_ptr(), grh.data_ptr(), per,
+                                d_pre.data_ptr(), acc.data_ptr(), 1, N, per, RC_F32,
+                                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "rc_gru_gate_r_bwd")
+    dr, dh = U.gru_gate_r_bwd(g["rc"], g["ctx"][:, C:2 * C], g["h"], grh.cpu().numpy())
+    assert rel(d_pre, dr) < TOL32
+    assert rel(acc - base, dh) < 1e-5
+
+
+# ------------------------------------------------------------------ ConvGRUHip end to end (torch convolutions)
+@pytest.mark.parametrize("case", GRU_CASES)
+def test_convgru_module_matches_reference(R, golden, case):
+    g = golden(case)
+    C, nx = int(g["C"]), int(g["n_x"])
+    xdim = sum(g[f"x{i}"].shape[1] for i in range(nx))
+    gru = R.ConvGRUHip(C, xdim).cuda()
+    gru.load_state_dict({k[2:]: dev(v) for k, v in g.items() if k.startswith("w_")})   # reference names
+    ctx = dev(g["ctx"]).requires_grad_(True)
+    h = dev(g["h"]).requires_grad_(True)
+    xs = [dev(g[f"x{i}"]).requires_grad_(True) for i in range(nx)]
+    out = gru(h, *ctx.split(split_size=C, dim=1), *xs)
+    assert rel(out, g["h_out"]) < TOL_CONV
+    out.backward(dev(g["grad_out"]))
+    assert rel(h.grad, g["d_h"]) < TOL_CONV
+    assert rel(ctx.grad, g["d_ctx"]) < TOL_CONV
+    for i, x in enumerate(xs):
+        assert rel(x.grad, g[f"d_x{i}"]) < TOL_CONV
+    for k, p in gru.named_parameters():
+        assert rel(p.grad, g["dw_" + k]) < TOL_CONV, k
+    with torch.no_grad():          # the inference route writes r*h in place into its own [h, x] copy
+        out2 = gru(h.detach(), *ctx.detach().split(split_size=C, dim=1), *[x.detach() for x in xs])
+    assert rel(out2, g["h_out"]) < TOL_CONV
+    assert rel(h, g["h"]) == 0.0
+
+
+# ------------------------------------------------------------------ 16-bit: per-operation rounding
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("case", GRU_CASES)
+def test_gru_kernels_16bit(R, golden, case, dtype):
+    g = golden(case)
+    C = int(g["C"])
+    rd = _rounder(dtype)
+    _, (cz, cr, cq) = _ctx_views(g, dtype)
+    h = dev(g["h"], dtype)
+    out = R.gru_update(dev(g["zc"], dtype), cz, dev(g["qc"], dtype), cq, h)
+    assert out.dtype == dtype
+    ref = U.gru_update(g["zc"], g["ctx"][:, :C], g["qc"], g["ctx"][:, 2 * C:], g["h"], round_to=rd)
+    assert rel(out, ref) < TOL16[dtype]
+    rh = R.gru_gate_r(dev(g["rc"], dtype), cr, h)
+    assert rel(rh, U.gru_gate_r(g["rc"], g["ctx"][:, C:2 * C], g["h"], round_to=rd)) < TOL16[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_gru_kernels_equal_torch_ops_at_full_size(R, dtype):
+    """KITTI share of one GPU: net[0] is [8,128,96,312].  The chain of torch ops of core/update.py:27-31 on the
+    same device is the second reference here (same per-operation rounding), forward and backward."""
+    torch.manual_seed(5)
+    shp = (8, 128, 96, 312)
+    ctx = torch.randn(shp[0], 3 * shp[1], *shp[2:], device="cuda", dtype=dtype)
+    cz, cr, cq = ctx.split(split_size=shp[1], dim=1)
+    zc, rc, qc = (torch.randn(shp, device="cuda", dtype=dtype) * 2 for _ in range(3))
+    h = torch.tanh(torch.randn(shp, device="cuda", dtype=dtype))
+    tol = TOL32 if dtype == torch.float32 else TOL16[dtype]
+    z = torch.sigmoid(zc + cz)
+    r = torch.sigmoid(rc + cr)
+    q = torch.tanh(qc + cq)
+    ref = (1 - z) * h + z * q
+    assert rel(R.gru_update(zc, cz, qc, cq, h), ref.float().cpu().numpy()) < tol
+    assert rel(R.gru_gate_r(rc, cr, h), (r * h).float().cpu().numpy()) < tol
+    if dtype == torch.float32:
+        leaves = [t.clone().requires_grad_(True) for t in (zc, qc, h)]
+        gout = torch.randn(shp, device="cuda")
+        R.gru_update(leaves[0], cz, leaves[1], cq, leaves[2]).backward(gout)
+        mine = [t.grad.clone() for t in leaves]
+        ref_leaves = [t.clone().requires_grad_(True) for t in (zc, qc, h)]
+        z2, q2 = torch.sigmoid(ref_leaves[0] + cz), torch.tanh(ref_leaves[1] + cq)
+        ((1 - z2) * ref_leaves[2] + z2 * q2).backward(gout)
+        for a, b in zip(mine, ref_leaves):
+            assert rel(a, b.grad.cpu().numpy()) < TOL32
+
+
+# ------------------------------------------------------------------ convex upsampling
+@pytest.mark.parametrize("case", UPSAMPLE_CASES)
+def test_upsample_fp32_matches_reference(R, golden, case):
+    g = golden(case)
+    nd = int(g["n_downsample"])
+    with torch.no_grad():
+        up = R.upsample_flow_hip(dev(g["flow"]), dev(g["mask"]), nd)
+        assert up.dtype == torch.float32 and tuple(up.shape) == g["up"].shape
+        assert rel(up, g["up"]) < TOL32
+        up1 = R.upsample_flow_hip(dev(g["flow"]), dev(g["mask"]), nd, channels=1)   # raft_stereo.py:134
+        assert torch.equal(up1, up[:, :1])
+
+
+@pytest.mark.parametrize("case", UPSAMPLE_CASES)
+def test_upsample_16bit_mask(R, golden, case):
+    g = golden(case)
+    nd = int(g["n_downsample"])
+    with torch.no_grad():
+        up = R.upsample_flow_hip(dev(g["flow"]), dev(g["mask"], torch.float16), nd)
+        assert rel(up, g["up_mask16"]) < TOL16[torch.float16]        # the reference on the fp16 mask
+        ref = U.upsample_flow(g["flow"], _round(g["mask"], torch.float16), 2 ** nd, round_to=np.float16)
+        assert rel(up, ref) < 1e-3                                    # one fp16 ulp of a probability
+        upb = R.upsample_flow_hip(dev(g["flow"]), dev(g["mask"], torch.bfloat16), nd)
+        refb = U.upsample_flow(g["flow"], _round(g["mask"], torch.bfloat16), 2 ** nd,
+                               round_to=_rounder(torch.bfloat16))
+        assert rel(upb, refb) < 8e-3
+
+
+@pytest.mark.parametrize("nd,shape", [(2, (8, 96, 312)), (3, (1, 60, 80)), (2, (1, 504, 752))])
+def test_upsample_full_size_properties(R, nd, shape):
+    """Size-independent properties at BASELINE sizes: (1) equal logits -> f x the zero-padded 3x3 box mean;
+    (2) a constant field stays constant (x f) away from the border; (3) fx/fy placement: a mask that puts all
+    weight on the centre tap replicates f*flow into f x f blocks."""
+    torch.manual_seed(3)
+    N, H, W = shape
+    f = 2 ** nd
+    flow = torch.randn(N, 2, H, W, device="cuda") * 4
+    with torch.no_grad():
+        zeros = torch.zeros(N, 9 * f * f, H, W, device="cuda", dtype=torch.float16)
+        up = R.upsample_flow_hip(flow, zeros, nd)
+        box = torch.nn.functional.avg_pool2d(f * flow, 3, stride=1, padding=1, count_include_pad=True)
+        # 1/9 is rounded to fp16 (the mask's type) before the products
+        w9 = float(torch.tensor(1.0 / 9).half())
+        expect = (box * 9 * w9).repeat_interleave(f, dim=2).repeat_interleave(f, dim=3)
+        assert rel(up, expect.cpu().numpy()) < 1e-5
+        const = torch.full((N, 2, H, W), 1.5, device="cuda")
+        mask = torch.randn(N, 9 * f * f, H, W, device="cuda")
+        upc = R.upsample_flow_hip(const, mask, nd)
+        assert (upc[:, :, f:-f, f:-f] - 1.5 * f).abs().max().item() < 1e-4
+        centre = torch.full((N, 9, f * f, H, W), -1e4, device="cuda")
+        centre[:, 4] = 0
+        upk = R.upsample_flow_hip(flow, centre.view(N, 9 * f * f, H, W), nd)
+        assert torch.equal(upk, (f * flow).repeat_interleave(f, dim=2).repeat_interleave(f, dim=3))
+
+
+def test_update_argument_errors(R):
+    h = torch.zeros(1, 4, 2, 2)
+    with pytest.raises(RuntimeError):
+        R.gru_update(h, h, h, h, h)                       # CPU tensors: no fallback
+    with pytest.raises(RuntimeError):
+        R.upsample_flow_hip(torch.zeros(1, 2, 2, 2), torch.zeros(1, 144, 2, 2), 2)
+    hc = h.cuda()
+    with pytest.raises(ValueError):
+        R.gru_update(hc, hc, hc, hc[:, :2], hc)           # shape mismatch
+    with pytest.raises(ValueError):
+        with torch.no_grad():
+            R.upsample_flow_hip(torch.zeros(1, 2, 2, 2).cuda(), torch.zeros(1, 100, 2, 2).cuda(), 2)
+    with pytest.raises(RuntimeError):
+        R.upsample_flow_hip(torch.zeros(1, 2, 2, 2).cuda().requires_grad_(True), torch.zeros(1, 144, 2, 2).cuda(), 2)
+    from raft_stereo_amd._lib import lib
+    assert lib.rc_upsample_flow_fwd(None, 0, None, None, 1, 1, 1, 1, 4, 0, None) != 0
+    assert lib.rc_upsample_flow_fwd(1, 8, 1, 16, 1, 2, 2, 2, 3, 0, None) != 0      # factor 3
+    assert lib.rc_gru_update(None, None, 0, None, None, 0, None, None, 1, 1, 0, None) != 0

@@ -135,3 +135,61 @@ def test_reg_torch_port_matches_golden(golden):
     for kind in KINDS:
         out = blk(torch.from_numpy(g[f"coords_{kind}"])).numpy()
         assert O.rel_to_max(out, g[f"lookup_{kind}"]) < 2e-6
+
+
+# ----------------------------------------------------------------------------- GRU gates, upsampling
+from conftest import GRU_CASES, UPSAMPLE_CASES  # noqa: E402
+from oracle import update_oracle as U  # noqa: E402
+
+
+def _gru_ctx(g):
+    C = int(g["C"])
+    return g["ctx"][:, :C], g["ctx"][:, C:2 * C], g["ctx"][:, 2 * C:]
+
+
+@pytest.mark.parametrize("case", GRU_CASES)
+def test_gru_pointwise_matches_reference_convgru(golden, case):
+    """The oracle's gate arithmetic on the convolution outputs the reference's ConvGRU produced gives the
+    reference's new hidden state (core/update.py:27-31), and its adjoints give the reference's autograd
+    gradients at the convolution outputs."""
+    g = golden(case)
+    cz, cr, cq = _gru_ctx(g)
+    assert U.rel_to_max(U.gru_update(g["zc"], cz, g["qc"], cq, g["h"]), g["h_out"]) <= 1e-6
+    dz, dq, dh_u = U.gru_update_bwd(g["zc"], cz, g["qc"], cq, g["h"], g["grad_out"])
+    assert U.rel_to_max(dz, g["d_zc"]) <= 1e-5
+    assert U.rel_to_max(dq, g["d_qc"]) <= 1e-5
+    # d ctx = the three pre-activation gradients side by side (cz/cr/cq are split views, raft_stereo.py:88)
+    C = int(g["C"])
+    assert U.rel_to_max(dz, g["d_ctx"][:, :C]) <= 1e-5
+    assert U.rel_to_max(g["d_rc"], g["d_ctx"][:, C:2 * C]) <= 1e-6
+    assert U.rel_to_max(dq, g["d_ctx"][:, 2 * C:]) <= 1e-5
+    # r*h is what convq read in its first C input channels, so d(r*h) is the input gradient of that
+    # convolution; with it the gate adjoint must give the reference's d_rc, and the three routes into h
+    # (blend, r*h, the z/r convolutions' input) must add up to the reference's d_h
+    import torch
+    from torch.nn.grad import conv2d_input
+
+    def conv_in_grad(d_out, w):
+        shape = (d_out.shape[0], w.shape[1]) + d_out.shape[2:]
+        return conv2d_input(shape, torch.from_numpy(w), torch.from_numpy(d_out), padding=1).numpy()
+    d_rh = conv_in_grad(g["d_qc"], g["w_convq.weight"])[:, :C]
+    dr, dh_r = U.gru_gate_r_bwd(g["rc"], cr, g["h"], d_rh)
+    assert U.rel_to_max(dr, g["d_rc"]) <= 1e-5
+    d_h = dh_u + dh_r + conv_in_grad(g["d_zc"], g["w_convz.weight"])[:, :C] \
+        + conv_in_grad(g["d_rc"], g["w_convr.weight"])[:, :C]
+    assert U.rel_to_max(d_h, g["d_h"]) <= 1e-5
+    # forward of the gate: the reference's convq read [r*h, x] (update.py:29) and produced qc
+    rhx = np.concatenate([U.gru_gate_r(g["rc"], cr, g["h"])] + [g[f"x{i}"] for i in range(int(g["n_x"]))], axis=1)
+    qc = torch.nn.functional.conv2d(torch.from_numpy(rhx), torch.from_numpy(g["w_convq.weight"]),
+                                    torch.from_numpy(g["w_convq.bias"]), padding=1).numpy()
+    assert U.rel_to_max(qc, g["qc"]) <= 1e-5
+
+
+@pytest.mark.parametrize("case", UPSAMPLE_CASES)
+def test_upsample_matches_reference(golden, case):
+    g = golden(case)
+    f = 2 ** int(g["n_downsample"])
+    assert U.rel_to_max(U.upsample_flow(g["flow"], g["mask"], f), g["up"]) <= 1e-6
+    # fp16 mask (autocast): softmax returns fp16 probabilities
+    assert U.rel_to_max(U.upsample_flow(g["flow"], g["mask"].astype(np.float16), f, round_to=np.float16),
+                        g["up_mask16"]) <= 2e-3
