@@ -172,6 +172,63 @@ def fused_convc1(step, cfg, device, n=50):
                 fused_lookup_convc1_gbps=round(alg / (fused * 1e-6) / 1e9, 1))
 
 
+def update_ops(cfg, device, n=50):
+    """SURVEY 8(f) ranks 3 and 4, measured beside the contract's metric: the ConvGRU gate arithmetic on the
+    1/f-resolution hidden state ([B,128,H,W], core/update.py:27-31) as two library kernels against the same
+    chain of torch ops, and the convex upsampling (core/raft_stereo.py:55-67) against its torch ops.  HIP
+    events on the current stream; algorithmic bytes = every operand once."""
+    import raft_stereo_amd as R
+    dt = DTYPES[cfg["dtype"]]
+    s = 4 if cfg["dtype"] == "f32" else 2
+    B, H, W, C = cfg["batch"], cfg["H"], cfg["W"], 128
+    nd = 3 if W * 8 <= 640 else 2          # realtime runs at 1/8 resolution, everything else at 1/4
+    f = 2 ** nd
+    g = torch.Generator(device=device).manual_seed(99)
+    ctx = torch.randn((B, 3 * C, H, W), generator=g, device=device).to(dt)
+    cz, cr, cq = ctx.split(split_size=C, dim=1)
+    zc, rc, qc = (torch.randn((B, C, H, W), generator=g, device=device).to(dt) for _ in range(3))
+    h = torch.tanh(torch.randn((B, C, H, W), generator=g, device=device)).to(dt)
+    flow = torch.randn((B, 2, H, W), generator=g, device=device) * 4
+    mask = torch.randn((B, 9 * f * f, H, W), generator=g, device=device).to(dt)
+
+    def timed(fn):
+        for _ in range(5):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            fn()
+        b.record()
+        b.synchronize()
+        return a.elapsed_time(b) / n * 1e3
+
+    def torch_gru():
+        z = torch.sigmoid(zc + cz)
+        r = torch.sigmoid(rc + cr)
+        rh = r * h
+        q = torch.tanh(qc + cq)
+        return rh, (1 - z) * h + z * q
+
+    def torch_up():
+        m = torch.softmax(mask.view(B, 1, 9, f, f, H, W), dim=2)
+        u = torch.nn.functional.unfold(f * flow, [3, 3], padding=1).view(B, 2, 9, 1, 1, H, W)
+        return torch.sum(m * u, dim=2).permute(0, 1, 4, 2, 5, 3).reshape(B, 2, f * H, f * W)[:, :1]
+
+    with torch.no_grad():
+        t_upd = timed(lambda: R.gru_update(zc, cz, qc, cq, h))
+        t_gate = timed(lambda: R.gru_gate_r(rc, cr, h))
+        t_torch = timed(torch_gru)
+        t_up = timed(lambda: R.upsample_flow_hip(flow, mask, nd, channels=1))
+        t_up_torch = timed(torch_up)
+    el = B * C * H * W
+    up_bytes = B * H * W * (9 * f * f * s + 4 + f * f * 4)
+    return dict(gru_update_us=round(t_upd, 2), gru_update_gbps=round(6 * el * s / (t_upd * 1e-6) / 1e9, 1),
+                gru_gate_r_us=round(t_gate, 2), gru_gate_r_gbps=round(4 * el * s / (t_gate * 1e-6) / 1e9, 1),
+                gru_pointwise_torch_us=round(t_torch, 2),
+                upsample_us=round(t_up, 2), upsample_gbps=round(up_bytes / (t_up * 1e-6) / 1e9, 1),
+                upsample_torch_us=round(t_up_torch, 2))
+
+
 def hip_graph_step(step, n=50):
     """The same step (build/prepare + lookups) captured once in a HIP graph and replayed: what a
     caller that captures its GRU loop pays per pair batch once launch overhead is gone.  Reported
@@ -316,6 +373,8 @@ def main():
 
     if not is_alt and not cfg["train"] and rank == 0:
         extra.update(fused_convc1(step, cfg, device))      # after the timed region: not part of `value`
+    if not cfg["train"] and rank == 0 and cfg["H"] * cfg["W"] * cfg["batch"] <= 300000:
+        extra.update(update_ops(cfg, device))              # side metrics, after the timed region
     if not cfg["train"] and world == 1:       # side metric; kept out of multi-rank runs (no capture beside RCCL)
         extra.update(hip_graph_step(step))
 

@@ -272,6 +272,19 @@ int rc_gru_gate_r_bwd(const void* convr_out, const void* cr, int64_t cr_batch_st
 int rc_upsample_flow_fwd(const float* flow, int64_t flow_batch_stride, const void* mask, float* out,
                          int64_t N, int channels, int64_t H, int64_t W, int factor, int mask_dtype,
                          void* stream);
+/*
+ * Its adjoint (autograd of core/raft_stereo.py:59-67, run once per GRU iteration in training):
+ * grad_out float [N, channels, f*H, f*W] -> grad_mask [N, 9*f*f, H, W] of mask_dtype (softmax backward,
+ * rounded where the reference's 16-bit tensors round) and grad_flow float, `channels` planes per image,
+ * images grad_flow_batch_stride elements apart (planes beyond `channels` are not touched).  `work` is
+ * scratch of rc_upsample_flow_bwd_work_bytes() (the per-pixel, per-neighbour sums that the second kernel
+ * gathers into grad_flow: no atomics, reproducible run to run).
+ */
+int64_t rc_upsample_flow_bwd_work_bytes(int64_t N, int channels, int64_t H, int64_t W);
+int rc_upsample_flow_bwd(const float* flow, int64_t flow_batch_stride, const void* mask,
+                         const float* grad_out, void* grad_mask, float* grad_flow,
+                         int64_t grad_flow_batch_stride, void* work, int64_t N, int channels,
+                         int64_t H, int64_t W, int factor, int mask_dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -12,6 +12,7 @@ tree, which is NOT shipped):
   gru_update_bwd,
   gru_gate_r_bwd    autograd of the same lines
   upsample_flow     core/raft_stereo.py:55-67 softmax over 9, unfold(factor*flow, 3x3, padding=1), sum, permute
+  upsample_flow_bwd autograd of the same lines
 
 Parity pin: tests/test_oracle_golden.py checks these against vectors captured from the reference's own
 Python (tests/golden/make_golden_update.py ran `core.update.ConvGRU` and `RAFTStereo.upsample_flow` on
@@ -93,6 +94,34 @@ def upsample_flow(flow, mask, factor, round_to=None):
         nb = pad[:, :, ky:ky + H, kx:kx + W]                                # [N,D,H,W]
         out += p[:, None, k] * nb[:, :, None, None]
     return np.ascontiguousarray(out.transpose(0, 1, 4, 2, 5, 3)).reshape(N, D, f * H, f * W)
+
+
+def upsample_flow_bwd(flow, mask, factor, grad_out, round_to=None):
+    """Adjoint of upsample_flow (autograd of core/raft_stereo.py:59-67): (d flow, d mask).
+
+    The gradient of the probabilities (sum over D of grad * unfold(f*flow)) and the softmax backward
+    p * (gp - sum p gp) are rounded to the mask's storage type where torch's 16-bit tensors round."""
+    rd = _rounder(round_to)
+    flow = np.asarray(flow, dtype=F32)
+    N, D, H, W = flow.shape
+    f = factor
+    m = rd(mask).reshape(N, 9, f, f, H, W).astype(np.float64)
+    m = m - m.max(axis=1, keepdims=True)
+    e = np.exp(m)
+    p = rd((e / e.sum(axis=1, keepdims=True)).astype(F32)).astype(np.float64)       # [N,9,f,f,H,W]
+    g = np.asarray(grad_out, np.float64).reshape(N, D, H, f, W, f).transpose(0, 1, 3, 5, 2, 4)  # [N,D,f,f,H,W]
+    pad = np.zeros((N, D, H + 2, W + 2), dtype=np.float64)
+    pad[:, :, 1:-1, 1:-1] = F32(f) * flow
+    gp = np.zeros((N, 9, f, f, H, W), dtype=np.float64)
+    dpad = np.zeros_like(pad)
+    for k in range(9):
+        ky, kx = divmod(k, 3)
+        nb = pad[:, :, ky:ky + H, kx:kx + W]                                          # [N,D,H,W]
+        gp[:, k] = (g * nb[:, :, None, None]).sum(axis=1)
+        dpad[:, :, ky:ky + H, kx:kx + W] += (p[:, None, k] * g).sum(axis=(2, 3))
+    gp = rd(gp.astype(F32)).astype(np.float64)
+    dmask = rd((p * (gp - (p * gp).sum(axis=1, keepdims=True))).astype(F32)).reshape(N, 9 * f * f, H, W)
+    return (f * dpad[:, :, 1:-1, 1:-1]).astype(F32), dmask
 
 
 def rel_to_max(a, b):

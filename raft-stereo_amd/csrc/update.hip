@@ -22,7 +22,16 @@ constexpr int PW_THREADS = 256;
 // result to the tensor type.  rnd<T>() marks each of those roundings (identity for float).
 template <typename T> __device__ __forceinline__ float rnd(float v) { return rc_round_as<T>(v); }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// f32 tensors take the accurate library functions; for 16-bit tensors, whose results are rounded to 11 or 8
+// bits anyway, v_exp_f32 / v_rcp_f32 (about 1 ulp of fp32 each) keep the kernels off the VALU roof
+template <typename T> __device__ __forceinline__ float sigmoid_t(float x) {
+  if constexpr (sizeof(T) == 4) return 1.0f / (1.0f + expf(-x));
+  else return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+}
+template <typename T> __device__ __forceinline__ float tanh_t(float x) {
+  if constexpr (sizeof(T) == 4) return tanhf(x);
+  else return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f);
+}
 
 template <typename T, int VEC> struct pw_vec {
   typedef T type __attribute__((ext_vector_type(VEC)));
@@ -46,9 +55,9 @@ __global__ __launch_bounds__(PW_THREADS) void gru_gate_r_kernel(const T* __restr
                                                                 int64_t cr_bs, const T* __restrict__ h,
                                                                 T* __restrict__ rh, int64_t rh_bs, int64_t per_batch,
                                                                 int64_t total) {
-  const int64_t e = ((int64_t)blockIdx.x * PW_THREADS + threadIdx.x) * VEC;
-  if (e >= total) return;
-  const int64_t b = e / per_batch, i = e - b * per_batch;
+  const int64_t i = ((int64_t)blockIdx.x * PW_THREADS + threadIdx.x) * VEC;  // inside image b = blockIdx.y
+  if (i >= per_batch) return;
+  const int64_t b = blockIdx.y, e = b * per_batch + i;
   const auto a = pw_load<T, VEC>(convr + e);
   const auto c = pw_load<T, VEC>(cr + b * cr_bs + i);
   const auto hv = pw_load<T, VEC>(h + e);
@@ -56,7 +65,7 @@ __global__ __launch_bounds__(PW_THREADS) void gru_gate_r_kernel(const T* __restr
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
     const float s = rnd<T>(rc_to_float(a[j]) + rc_to_float(c[j]));
-    const float r = rnd<T>(sigmoidf_(s));
+    const float r = rnd<T>(sigmoid_t<T>(s));
     o[j] = rc_from_float<T>(r * rc_to_float(hv[j]));
   }
   *reinterpret_cast<typename pw_vec<T, VEC>::type*>(rh + b * rh_bs + i) = o;
@@ -69,9 +78,9 @@ __global__ __launch_bounds__(PW_THREADS) void gru_update_kernel(const T* __restr
                                                                 const T* __restrict__ cq, int64_t cq_bs,
                                                                 const T* h, T* h_out, int64_t per_batch,
                                                                 int64_t total) {
-  const int64_t e = ((int64_t)blockIdx.x * PW_THREADS + threadIdx.x) * VEC;
-  if (e >= total) return;
-  const int64_t b = e / per_batch, i = e - b * per_batch;
+  const int64_t i = ((int64_t)blockIdx.x * PW_THREADS + threadIdx.x) * VEC;  // inside image b = blockIdx.y
+  if (i >= per_batch) return;
+  const int64_t b = blockIdx.y, e = b * per_batch + i;
   const auto az = pw_load<T, VEC>(convz + e);
   const auto bz = pw_load<T, VEC>(cz + b * cz_bs + i);
   const auto aq = pw_load<T, VEC>(convq + e);
@@ -80,8 +89,8 @@ __global__ __launch_bounds__(PW_THREADS) void gru_update_kernel(const T* __restr
   typename pw_vec<T, VEC>::type o;
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
-    const float z = rnd<T>(sigmoidf_(rnd<T>(rc_to_float(az[j]) + rc_to_float(bz[j]))));
-    const float q = rnd<T>(tanhf(rnd<T>(rc_to_float(aq[j]) + rc_to_float(bq[j]))));
+    const float z = rnd<T>(sigmoid_t<T>(rnd<T>(rc_to_float(az[j]) + rc_to_float(bz[j]))));
+    const float q = rnd<T>(tanh_t<T>(rnd<T>(rc_to_float(aq[j]) + rc_to_float(bq[j]))));
     const float keep = rnd<T>(rnd<T>(1.0f - z) * rc_to_float(hv[j]));
     const float take = rnd<T>(z * q);
     o[j] = rc_from_float<T>(keep + take);
@@ -96,9 +105,9 @@ __global__ __launch_bounds__(PW_THREADS) void gru_update_bwd_kernel(
     const T* __restrict__ convz, const T* __restrict__ cz, int64_t cz_bs, const T* __restrict__ convq,
     const T* __restrict__ cq, int64_t cq_bs, const T* __restrict__ h, const T* __restrict__ gout,
     T* __restrict__ dzpre, T* __restrict__ dqpre, T* __restrict__ dh, int64_t per_batch, int64_t total) {
-  const int64_t e = ((int64_t)blockIdx.x * PW_THREADS + threadIdx.x) * VEC;
-  if (e >= total) return;
-  const int64_t b = e / per_batch, i = e - b * per_batch;
+  const int64_t i = ((int64_t)blockIdx.x * PW_THREADS + threadIdx.x) * VEC;  // inside image b = blockIdx.y
+  if (i >= per_batch) return;
+  const int64_t b = blockIdx.y, e = b * per_batch + i;
   const auto az = pw_load<T, VEC>(convz + e);
   const auto bz = pw_load<T, VEC>(cz + b * cz_bs + i);
   const auto aq = pw_load<T, VEC>(convq + e);
@@ -108,8 +117,8 @@ __global__ __launch_bounds__(PW_THREADS) void gru_update_bwd_kernel(
   typename pw_vec<T, VEC>::type oz, oq, oh;
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
-    const float z = rnd<T>(sigmoidf_(rnd<T>(rc_to_float(az[j]) + rc_to_float(bz[j]))));
-    const float q = rnd<T>(tanhf(rnd<T>(rc_to_float(aq[j]) + rc_to_float(bq[j]))));
+    const float z = rnd<T>(sigmoid_t<T>(rnd<T>(rc_to_float(az[j]) + rc_to_float(bz[j]))));
+    const float q = rnd<T>(tanh_t<T>(rnd<T>(rc_to_float(aq[j]) + rc_to_float(bq[j]))));
     const float g = rc_to_float(gv[j]), hh = rc_to_float(hv[j]);
     oz[j] = rc_from_float<T>(g * (q - hh) * z * (1.0f - z));
     oq[j] = rc_from_float<T>(g * z * (1.0f - q * q));
@@ -128,9 +137,9 @@ __global__ __launch_bounds__(PW_THREADS) void gru_gate_r_bwd_kernel(const T* __r
                                                                     const T* __restrict__ h, const T* __restrict__ grh,
                                                                     int64_t grh_bs, T* __restrict__ drpre, T* dh,
                                                                     int dh_accum, int64_t per_batch, int64_t total) {
-  const int64_t e = ((int64_t)blockIdx.x * PW_THREADS + threadIdx.x) * VEC;
-  if (e >= total) return;
-  const int64_t b = e / per_batch, i = e - b * per_batch;
+  const int64_t i = ((int64_t)blockIdx.x * PW_THREADS + threadIdx.x) * VEC;  // inside image b = blockIdx.y
+  if (i >= per_batch) return;
+  const int64_t b = blockIdx.y, e = b * per_batch + i;
   const auto a = pw_load<T, VEC>(convr + e);
   const auto c = pw_load<T, VEC>(cr + b * cr_bs + i);
   const auto hv = pw_load<T, VEC>(h + e);
@@ -140,7 +149,7 @@ __global__ __launch_bounds__(PW_THREADS) void gru_gate_r_bwd_kernel(const T* __r
   typename pw_vec<T, VEC>::type orr, oh;
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
-    const float r = rnd<T>(sigmoidf_(rnd<T>(rc_to_float(a[j]) + rc_to_float(c[j]))));
+    const float r = rnd<T>(sigmoid_t<T>(rnd<T>(rc_to_float(a[j]) + rc_to_float(c[j]))));
     const float g = rc_to_float(gv[j]);
     orr[j] = rc_from_float<T>(g * rc_to_float(hv[j]) * r * (1.0f - r));
     const float d = g * r;
@@ -152,10 +161,11 @@ __global__ __launch_bounds__(PW_THREADS) void gru_gate_r_bwd_kernel(const T* __r
 
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
-inline int pw_blocks(int64_t total, int vec, unsigned* blocks) {
-  const int64_t n = (total / vec + PW_THREADS - 1) / PW_THREADS;
-  RC_REQUIRE(n < (1ll << 31), RC_EINVAL, "too many elements");
-  *blocks = (unsigned)n;
+inline int pw_blocks(int64_t N, int64_t per_batch, int vec, dim3* blocks) {
+  const int64_t n = (per_batch / vec + PW_THREADS - 1) / PW_THREADS;
+  RC_REQUIRE(n < (1ll << 31) && N < 65536, RC_EINVAL, "too many elements (N=%lld, per_batch=%lld)", (long long)N,
+             (long long)per_batch);
+  *blocks = dim3((unsigned)n, (unsigned)N);
   return RC_OK;
 }
 
@@ -173,14 +183,14 @@ int launch_gate_r(const void* convr, const void* cr, int64_t cr_bs, const void* 
   const int64_t total = N * per_batch;
   const bool vec = per_batch % V == 0 && cr_bs % V == 0 && rh_bs % V == 0 && aligned16(convr) && aligned16(cr) &&
                    aligned16(h) && aligned16(rh);
-  unsigned blocks;
-  int rc = pw_blocks(total, vec ? V : 1, &blocks);
+  dim3 blocks;
+  int rc = pw_blocks(N, per_batch, vec ? V : 1, &blocks);
   if (rc) return rc;
   if (vec)
-    hipLaunchKernelGGL((gru_gate_r_kernel<T, V>), dim3(blocks), dim3(PW_THREADS), 0, st, (const T*)convr,
+    hipLaunchKernelGGL((gru_gate_r_kernel<T, V>), blocks, dim3(PW_THREADS), 0, st, (const T*)convr,
                        (const T*)cr, cr_bs, (const T*)h, (T*)rh, rh_bs, per_batch, total);
   else
-    hipLaunchKernelGGL((gru_gate_r_kernel<T, 1>), dim3(blocks), dim3(PW_THREADS), 0, st, (const T*)convr,
+    hipLaunchKernelGGL((gru_gate_r_kernel<T, 1>), blocks, dim3(PW_THREADS), 0, st, (const T*)convr,
                        (const T*)cr, cr_bs, (const T*)h, (T*)rh, rh_bs, per_batch, total);
   return rc_check_launch("rc_gru_gate_r");
 }
@@ -192,15 +202,15 @@ int launch_update(const void* convz, const void* cz, int64_t cz_bs, const void* 
   const int64_t total = N * per_batch;
   const bool vec = per_batch % V == 0 && cz_bs % V == 0 && cq_bs % V == 0 && aligned16(convz) && aligned16(cz) &&
                    aligned16(convq) && aligned16(cq) && aligned16(h) && aligned16(h_out);
-  unsigned blocks;
-  int rc = pw_blocks(total, vec ? V : 1, &blocks);
+  dim3 blocks;
+  int rc = pw_blocks(N, per_batch, vec ? V : 1, &blocks);
   if (rc) return rc;
   if (vec)
-    hipLaunchKernelGGL((gru_update_kernel<T, V>), dim3(blocks), dim3(PW_THREADS), 0, st, (const T*)convz,
+    hipLaunchKernelGGL((gru_update_kernel<T, V>), blocks, dim3(PW_THREADS), 0, st, (const T*)convz,
                        (const T*)cz, cz_bs, (const T*)convq, (const T*)cq, cq_bs, (const T*)h, (T*)h_out, per_batch,
                        total);
   else
-    hipLaunchKernelGGL((gru_update_kernel<T, 1>), dim3(blocks), dim3(PW_THREADS), 0, st, (const T*)convz,
+    hipLaunchKernelGGL((gru_update_kernel<T, 1>), blocks, dim3(PW_THREADS), 0, st, (const T*)convz,
                        (const T*)cz, cz_bs, (const T*)convq, (const T*)cq, cq_bs, (const T*)h, (T*)h_out, per_batch,
                        total);
   return rc_check_launch("rc_gru_update");
@@ -215,15 +225,15 @@ int launch_update_bwd(const void* convz, const void* cz, int64_t cz_bs, const vo
   const bool vec = per_batch % V == 0 && cz_bs % V == 0 && cq_bs % V == 0 && aligned16(convz) && aligned16(cz) &&
                    aligned16(convq) && aligned16(cq) && aligned16(h) && aligned16(gout) && aligned16(dz) &&
                    aligned16(dq) && aligned16(dh);
-  unsigned blocks;
-  int rc = pw_blocks(total, vec ? V : 1, &blocks);
+  dim3 blocks;
+  int rc = pw_blocks(N, per_batch, vec ? V : 1, &blocks);
   if (rc) return rc;
   if (vec)
-    hipLaunchKernelGGL((gru_update_bwd_kernel<T, V>), dim3(blocks), dim3(PW_THREADS), 0, st, (const T*)convz,
+    hipLaunchKernelGGL((gru_update_bwd_kernel<T, V>), blocks, dim3(PW_THREADS), 0, st, (const T*)convz,
                        (const T*)cz, cz_bs, (const T*)convq, (const T*)cq, cq_bs, (const T*)h, (const T*)gout,
                        (T*)dz, (T*)dq, (T*)dh, per_batch, total);
   else
-    hipLaunchKernelGGL((gru_update_bwd_kernel<T, 1>), dim3(blocks), dim3(PW_THREADS), 0, st, (const T*)convz,
+    hipLaunchKernelGGL((gru_update_bwd_kernel<T, 1>), blocks, dim3(PW_THREADS), 0, st, (const T*)convz,
                        (const T*)cz, cz_bs, (const T*)convq, (const T*)cq, cq_bs, (const T*)h, (const T*)gout,
                        (T*)dz, (T*)dq, (T*)dh, per_batch, total);
   return rc_check_launch("rc_gru_update_bwd");
@@ -237,15 +247,15 @@ int launch_gate_r_bwd(const void* convr, const void* cr, int64_t cr_bs, const vo
   const int64_t total = N * per_batch;
   const bool vec = per_batch % V == 0 && cr_bs % V == 0 && grh_bs % V == 0 && aligned16(convr) && aligned16(cr) &&
                    aligned16(h) && aligned16(grh) && aligned16(dr) && aligned16(dh);
-  unsigned blocks;
-  int rc = pw_blocks(total, vec ? V : 1, &blocks);
+  dim3 blocks;
+  int rc = pw_blocks(N, per_batch, vec ? V : 1, &blocks);
   if (rc) return rc;
   if (vec)
-    hipLaunchKernelGGL((gru_gate_r_bwd_kernel<T, V>), dim3(blocks), dim3(PW_THREADS), 0, st, (const T*)convr,
+    hipLaunchKernelGGL((gru_gate_r_bwd_kernel<T, V>), blocks, dim3(PW_THREADS), 0, st, (const T*)convr,
                        (const T*)cr, cr_bs, (const T*)h, (const T*)grh, grh_bs, (T*)dr, (T*)dh, dh_accum, per_batch,
                        total);
   else
-    hipLaunchKernelGGL((gru_gate_r_bwd_kernel<T, 1>), dim3(blocks), dim3(PW_THREADS), 0, st, (const T*)convr,
+    hipLaunchKernelGGL((gru_gate_r_bwd_kernel<T, 1>), blocks, dim3(PW_THREADS), 0, st, (const T*)convr,
                        (const T*)cr, cr_bs, (const T*)h, (const T*)grh, grh_bs, (T*)dr, (T*)dh, dh_accum, per_batch,
                        total);
   return rc_check_launch("rc_gru_gate_r_bwd");
@@ -327,14 +337,16 @@ __global__ __launch_bounds__(PW_THREADS) void upsample_kernel(const float* __res
       float e[9], s = 0.f;
 #pragma unroll
       for (int k = 0; k < 9; ++k) {
-        e[k] = expf(m[k][j] - mx);
+        if constexpr (sizeof(MT) == 4) e[k] = expf(m[k][j] - mx);
+        else e[k] = __expf(m[k][j] - mx);
         s += e[k];
       }
+      const float inv = sizeof(MT) == 4 ? 1.0f / s : __builtin_amdgcn_rcpf(s);
 #pragma unroll
       for (int c = 0; c < C; ++c) res[c][j] = 0.f;
 #pragma unroll
       for (int k = 0; k < 9; ++k) {
-        const float p = rc_round_as<MT>(e[k] / s);
+        const float p = rc_round_as<MT>(e[k] * inv);
 #pragma unroll
         for (int c = 0; c < C; ++c) res[c][j] += p * v[c][k];
       }
@@ -354,6 +366,179 @@ __global__ __launch_bounds__(PW_THREADS) void upsample_kernel(const float* __res
   }
 }
 
+// ---- adjoint of the upsampling (autograd of core/raft_stereo.py:59-67).  With g = d out, v_k = f * flow at
+// neighbour k and p = softmax(mask):
+//   a_k = sum_c g[c] v_k[c]  (rounded to the mask type: it is the gradient of the MT tensor `p`),
+//   d mask_k = p_k (a_k - sum_j p_j a_j),        t[c][k] = sum over (fy,fx) of p_k g[c]
+// Kernel A: a wave owns 64 low-resolution pixels of a row, walks their f x f output pixels, writes d mask
+// (same plane-wise runs as the forward's loads) and the 9 C sums t of each pixel into `work` [N,C,9,H,W].
+// Kernel B: d flow[c,h,w] = f * sum_k t[c][k] at the pixel whose k-th neighbour is (h,w): a gather, no atomics.
+template <typename MT, int F, int C>
+__global__ __launch_bounds__(PW_THREADS) void upsample_bwd_kernel(const float* __restrict__ flow, int64_t flow_bs,
+                                                                  const MT* __restrict__ mask,
+                                                                  const float* __restrict__ gout,
+                                                                  MT* __restrict__ dmask, float* __restrict__ work,
+                                                                  int H, int W, int chunks_per_row, int n_items) {
+  constexpr int G = F < 4 ? F : 4;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int item = blockIdx.x * (PW_THREADS / 64) + wave;  // (n*H + h)*chunks + chunk, wave-uniform
+  if (item >= n_items) return;
+  const int nh = item / chunks_per_row;
+  const int c0 = (item - nh * chunks_per_row) * 64;
+  const int n = nh / H, h = nh - n * H;
+  const int w = c0 + lane;
+  if (w >= W) return;
+  const int64_t HW = (int64_t)H * W;
+
+  float v[C][9], t[C][9];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int hh = h + ky - 1;
+    const bool rok = (unsigned)hh < (unsigned)H;
+    const float* frow = flow + up_uniform((int64_t)n * flow_bs + (int64_t)(rok ? hh : h) * W);
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ww = w + kx - 1;
+      const bool ok = rok && (unsigned)ww < (unsigned)W;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float f = (frow + (int64_t)c * HW)[ok ? ww : w];
+        v[c][ky * 3 + kx] = ok ? (float)F * f : 0.f;
+        t[c][ky * 3 + kx] = 0.f;
+      }
+    }
+  }
+
+  const int64_t mbase = up_uniform((int64_t)n * 9 * F * F * HW + (int64_t)h * W + c0);
+  const MT* mrow = mask + mbase;
+  MT* drow = dmask + mbase;
+  const float* grow = gout + up_uniform(((int64_t)n * C * H + h) * F * (int64_t)F * W + (int64_t)F * c0);
+  const uint32_t HWu = (uint32_t)HW;
+  for (int fy = 0; fy < F; ++fy) {
+#pragma unroll
+    for (int g0 = 0; g0 < F; g0 += G) {
+      float m[9][G];
+      const uint32_t pl0 = (uint32_t)(fy * F + g0);
+#pragma unroll
+      for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int j = 0; j < G; ++j) m[k][j] = rc_to_float(mrow[(uint32_t)(k * F * F + pl0 + j) * HWu + (uint32_t)lane]);
+      float gg[C][G];
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float* src = grow + up_uniform(((int64_t)c * H * F + fy) * (int64_t)F * W) + (uint32_t)(lane * F + g0);
+        const auto q = *reinterpret_cast<const typename up_vec<G>::type*>(src);
+        if constexpr (G == 1) {
+          gg[c][0] = q;
+        } else {
+#pragma unroll
+          for (int j = 0; j < G; ++j) gg[c][j] = q[j];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        float mx = m[0][j];
+#pragma unroll
+        for (int k = 1; k < 9; ++k) mx = fmaxf(mx, m[k][j]);
+        float e[9], s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          if constexpr (sizeof(MT) == 4) e[k] = expf(m[k][j] - mx);
+          else e[k] = __expf(m[k][j] - mx);
+          s += e[k];
+        }
+        const float inv = sizeof(MT) == 4 ? 1.0f / s : __builtin_amdgcn_rcpf(s);
+        float a[9], dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          e[k] = rc_round_as<MT>(e[k] * inv);  // p_k
+          float ak = 0.f;
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            ak += gg[c][j] * v[c][k];
+            t[c][k] += e[k] * gg[c][j];
+          }
+          a[k] = rc_round_as<MT>(ak);
+          dot += e[k] * a[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+          drow[(uint32_t)(k * F * F + pl0 + j) * HWu + (uint32_t)lane] = rc_from_float<MT>(e[k] * (a[k] - dot));
+      }
+    }
+  }
+  float* wrow = work + up_uniform((int64_t)n * C * 9 * HW + (int64_t)h * W + c0);
+#pragma unroll
+  for (int c = 0; c < C; ++c)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wrow[(uint32_t)(c * 9 + k) * HWu + (uint32_t)lane] = t[c][k];
+}
+
+template <int C>
+__global__ __launch_bounds__(PW_THREADS) void upsample_bwd_flow_kernel(const float* __restrict__ work,
+                                                                       float* __restrict__ dflow, int64_t dflow_bs,
+                                                                       int H, int W, float factor, int64_t total) {
+  const int64_t idx = (int64_t)blockIdx.x * PW_THREADS + threadIdx.x;  // (n, h, w)
+  if (idx >= total) return;
+  const int w = (int)(idx % W);
+  const int64_t r = idx / W;
+  const int h = (int)(r % H);
+  const int64_t n = r / H;
+  const int64_t HW = (int64_t)H * W;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int hs = h - (k / 3) + 1, ws = w - (k % 3) + 1;  // the pixel whose k-th neighbour is (h, w)
+      if ((unsigned)hs < (unsigned)H && (unsigned)ws < (unsigned)W)
+        acc += work[((n * C + c) * 9 + k) * HW + (int64_t)hs * W + ws];
+    }
+    dflow[n * dflow_bs + (int64_t)c * HW + (int64_t)h * W + w] = factor * acc;
+  }
+}
+
+template <typename MT, int F, int C>
+int launch_upsample_bwd(const float* flow, int64_t flow_bs, const void* mask, const float* gout, void* dmask,
+                        float* dflow, int64_t dflow_bs, float* work, int64_t N, int64_t H, int64_t W,
+                        hipStream_t st) {
+  const int chunks = (int)((W + 63) / 64);
+  const int64_t items = N * H * chunks;
+  RC_REQUIRE(items < (1ll << 31), RC_EINVAL, "too many pixels");
+  const int blocks = (int)((items + PW_THREADS / 64 - 1) / (PW_THREADS / 64));
+  hipLaunchKernelGGL((upsample_bwd_kernel<MT, F, C>), dim3(blocks), dim3(PW_THREADS), 0, st, flow, flow_bs,
+                     (const MT*)mask, gout, (MT*)dmask, work, (int)H, (int)W, chunks, (int)items);
+  int rc = rc_check_launch("rc_upsample_flow_bwd");
+  if (rc) return rc;
+  const int64_t total = N * H * W;
+  hipLaunchKernelGGL((upsample_bwd_flow_kernel<C>), dim3((unsigned)((total + PW_THREADS - 1) / PW_THREADS)),
+                     dim3(PW_THREADS), 0, st, work, dflow, dflow_bs, (int)H, (int)W, (float)F, total);
+  return rc_check_launch("rc_upsample_flow_bwd(flow)");
+}
+
+template <typename MT, int F>
+int launch_upsample_bwd_c(const float* flow, int64_t flow_bs, const void* mask, const float* gout, void* dmask,
+                          float* dflow, int64_t dflow_bs, float* work, int64_t N, int C, int64_t H, int64_t W,
+                          hipStream_t st) {
+  return C == 1 ? launch_upsample_bwd<MT, F, 1>(flow, flow_bs, mask, gout, dmask, dflow, dflow_bs, work, N, H, W, st)
+                : launch_upsample_bwd<MT, F, 2>(flow, flow_bs, mask, gout, dmask, dflow, dflow_bs, work, N, H, W, st);
+}
+
+template <typename MT>
+int launch_upsample_bwd_f(const float* flow, int64_t flow_bs, const void* mask, const float* gout, void* dmask,
+                          float* dflow, int64_t dflow_bs, float* work, int64_t N, int C, int64_t H, int64_t W,
+                          int factor, hipStream_t st) {
+  switch (factor) {
+    case 1: return launch_upsample_bwd_c<MT, 1>(flow, flow_bs, mask, gout, dmask, dflow, dflow_bs, work, N, C, H, W, st);
+    case 2: return launch_upsample_bwd_c<MT, 2>(flow, flow_bs, mask, gout, dmask, dflow, dflow_bs, work, N, C, H, W, st);
+    case 4: return launch_upsample_bwd_c<MT, 4>(flow, flow_bs, mask, gout, dmask, dflow, dflow_bs, work, N, C, H, W, st);
+    case 8: return launch_upsample_bwd_c<MT, 8>(flow, flow_bs, mask, gout, dmask, dflow, dflow_bs, work, N, C, H, W, st);
+  }
+  rc_set_error("upsampling factor %d is not one of 1, 2, 4, 8", factor);
+  return RC_EUNSUPPORTED;
+}
+
 template <typename MT, int F, int C>
 int launch_upsample(const float* flow, int64_t flow_bs, const void* mask, float* out, int64_t N, int64_t H,
                     int64_t W, hipStream_t st) {
@@ -361,7 +546,7 @@ int launch_upsample(const float* flow, int64_t flow_bs, const void* mask, float*
   const int64_t items = N * H * chunks * F;
   RC_REQUIRE(items < (1ll << 31), RC_EINVAL, "too many pixels");
   const int blocks = (int)((items + PW_THREADS / 64 - 1) / (PW_THREADS / 64));
-  hipLaunchKernelGGL((upsample_kernel<MT, F, C>), dim3(blocks), dim3(PW_THREADS), 0, st, flow, flow_bs,
+  hipLaunchKernelGGL((upsample_kernel<MT, F, C>), blocks, dim3(PW_THREADS), 0, st, flow, flow_bs,
                      (const MT*)mask, out, (int)H, (int)W, chunks, (int)items);
   return rc_check_launch("rc_upsample_flow_fwd");
 }
@@ -466,6 +651,42 @@ extern "C" int rc_upsample_flow_fwd(const float* flow, int64_t flow_batch_stride
     case RC_F32: return launch_upsample_f<float>(flow, flow_batch_stride, mask, out, N, channels, H, W, factor, st);
     case RC_F16: return launch_upsample_f<rc_half>(flow, flow_batch_stride, mask, out, N, channels, H, W, factor, st);
     case RC_BF16: return launch_upsample_f<rc_bf16>(flow, flow_batch_stride, mask, out, N, channels, H, W, factor, st);
+  }
+  rc_set_error("unknown mask dtype %d", mask_dtype);
+  return RC_EUNSUPPORTED;
+}
+
+extern "C" int64_t rc_upsample_flow_bwd_work_bytes(int64_t N, int channels, int64_t H, int64_t W) {
+  if (N <= 0 || H <= 0 || W <= 0 || (channels != 1 && channels != 2)) return -1;
+  return N * channels * 9 * H * W * (int64_t)sizeof(float);
+}
+
+extern "C" int rc_upsample_flow_bwd(const float* flow, int64_t flow_batch_stride, const void* mask,
+                                    const float* grad_out, void* grad_mask, float* grad_flow,
+                                    int64_t grad_flow_batch_stride, void* work, int64_t N, int channels, int64_t H,
+                                    int64_t W, int factor, int mask_dtype, void* stream) {
+  RC_REQUIRE(flow && mask && grad_out && grad_mask && grad_flow && work, RC_EINVAL, "null pointer argument");
+  RC_REQUIRE(N > 0 && H > 0 && W > 0, RC_EINVAL, "non-positive size N=%lld H=%lld W=%lld", (long long)N,
+             (long long)H, (long long)W);
+  RC_REQUIRE(channels == 1 || channels == 2, RC_EUNSUPPORTED, "channels must be 1 or 2 (got %d)", channels);
+  RC_REQUIRE(flow_batch_stride >= (int64_t)channels * H * W && grad_flow_batch_stride >= (int64_t)channels * H * W,
+             RC_EINVAL, "a flow batch stride is shorter than %d planes", channels);
+  RC_REQUIRE(factor >= 1 && (int64_t)9 * factor * factor * H * W < (1ll << 30), RC_EINVAL,
+             "one image's mask exceeds the 32-bit lane offset range");
+  RC_REQUIRE(((uintptr_t)grad_out & 15) == 0 && ((uintptr_t)work & 15) == 0, RC_EINVAL,
+             "grad_out and work must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  float* wk = (float*)work;
+  switch (mask_dtype) {
+    case RC_F32:
+      return launch_upsample_bwd_f<float>(flow, flow_batch_stride, mask, grad_out, grad_mask, grad_flow,
+                                          grad_flow_batch_stride, wk, N, channels, H, W, factor, st);
+    case RC_F16:
+      return launch_upsample_bwd_f<rc_half>(flow, flow_batch_stride, mask, grad_out, grad_mask, grad_flow,
+                                            grad_flow_batch_stride, wk, N, channels, H, W, factor, st);
+    case RC_BF16:
+      return launch_upsample_bwd_f<rc_bf16>(flow, flow_batch_stride, mask, grad_out, grad_mask, grad_flow,
+                                            grad_flow_batch_stride, wk, N, channels, H, W, factor, st);
   }
   rc_set_error("unknown mask dtype %d", mask_dtype);
   return RC_EUNSUPPORTED;

@@ -165,12 +165,39 @@ class ConvGRUHip(nn.Module):
         return gru_update(zc, cz, qc.to(dt), cq, h)                           # update.py:27,29,31
 
 
+class _UpsampleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, flow, mask, f, C):
+        N, D, H, W = flow.shape
+        with _on_device(flow.device):
+            out = torch.empty((N, C, f * H, f * W), dtype=torch.float32, device=flow.device)
+            check(lib.rc_upsample_flow_fwd(flow.data_ptr(), D * H * W, mask.data_ptr(), out.data_ptr(), N, C, H, W,
+                                           f, _DT[mask.dtype], _stream(flow.device)), "rc_upsample_flow_fwd")
+        ctx.save_for_backward(flow, mask)
+        ctx.f, ctx.C = f, C
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        flow, mask = ctx.saved_tensors
+        f, C = ctx.f, ctx.C
+        N, D, H, W = flow.shape
+        g = grad_out.float().contiguous()
+        with _on_device(flow.device):
+            d_mask = torch.empty_like(mask)
+            d_flow = torch.empty_like(flow) if C == D else torch.zeros_like(flow)
+            nbytes = lib.rc_upsample_flow_bwd_work_bytes(N, C, H, W)
+            work = torch.empty(int(nbytes), dtype=torch.uint8, device=flow.device)
+            check(lib.rc_upsample_flow_bwd(flow.data_ptr(), D * H * W, mask.data_ptr(), g.data_ptr(),
+                                           d_mask.data_ptr(), d_flow.data_ptr(), D * H * W, work.data_ptr(), N, C,
+                                           H, W, f, _DT[mask.dtype], _stream(flow.device)), "rc_upsample_flow_bwd")
+        return d_flow, d_mask, None, None
+
+
 def upsample_flow_hip(flow, mask, n_downsample, channels=None):
     """RAFTStereo.upsample_flow (core/raft_stereo.py:55-67): `[N, D, H, W]` flow and `[N, 9*f*f, H, W]` mask
     logits -> `[N, D, f*H, f*W]` fp32, f = 2**n_downsample.  `channels` = 1 computes only the x component (all
-    that core/raft_stereo.py:134 keeps).  Forward only."""
-    if torch.is_grad_enabled() and (flow.requires_grad or mask.requires_grad):
-        raise RuntimeError("upsample_flow_hip is forward-only: call it under torch.no_grad()")
+    that core/raft_stereo.py:134 keeps).  Differentiable w.r.t. flow and mask."""
     if not (flow.is_cuda and mask.is_cuda) or flow.device != mask.device:
         raise RuntimeError("upsample_flow_hip needs GPU tensors on one device (there is no CPU path)")
     if flow.dim() != 4 or mask.dim() != 4:
@@ -184,10 +211,4 @@ def upsample_flow_hip(flow, mask, n_downsample, channels=None):
         raise ValueError(f"mask must be [{N}, {9 * f * f}, {H}, {W}], got {tuple(mask.shape)}")
     if mask.dtype not in _DT:
         raise TypeError(f"unsupported mask dtype {mask.dtype}")
-    flow = flow.detach().float().contiguous()
-    mask = mask.detach().contiguous()
-    with _on_device(flow.device):
-        out = torch.empty((N, C, f * H, f * W), dtype=torch.float32, device=flow.device)
-        check(lib.rc_upsample_flow_fwd(flow.data_ptr(), D * H * W, mask.data_ptr(), out.data_ptr(), N, C, H, W, f,
-                                       _DT[mask.dtype], _stream(flow.device)), "rc_upsample_flow_fwd")
-    return out
+    return _UpsampleFn.apply(flow.float().contiguous(), mask.contiguous(), f, C)

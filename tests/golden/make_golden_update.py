@@ -89,7 +89,14 @@ def run_up(name, N, D, H, W, nd, seed):
     with torch.no_grad():
         rec = {"flow": flow, "mask": mask, "up": RAFTStereo.upsample_flow(me, flow, mask),
                "up_mask16": RAFTStereo.upsample_flow(me, flow, mask.half())}
-    rec = {k: v.numpy().copy() for k, v in rec.items()}
+    # autograd through the same method: fp32 mask, and the fp16 mask of the autocast case
+    gout = torch.randn_like(rec["up"])
+    rec["grad_out"] = gout
+    for tag, mk in (("", mask), ("_mask16", mask.half())):
+        fl, mk = flow.clone().requires_grad_(True), mk.clone().requires_grad_(True)
+        RAFTStereo.upsample_flow(me, fl, mk).backward(gout)
+        rec["d_flow" + tag], rec["d_mask" + tag] = fl.grad, mk.grad.float()
+    rec = {k: v.detach().numpy().copy() for k, v in rec.items()}
     rec["n_downsample"] = np.int64(nd)
     return rec
 

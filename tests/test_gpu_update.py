@@ -222,6 +222,49 @@ def test_upsample_16bit_mask(R, golden, case):
         assert rel(upb, refb) < 8e-3
 
 
+@pytest.mark.parametrize("case", UPSAMPLE_CASES)
+def test_upsample_backward_matches_reference_autograd(R, golden, case):
+    g = golden(case)
+    nd = int(g["n_downsample"])
+    flow, mask = dev(g["flow"]).requires_grad_(True), dev(g["mask"]).requires_grad_(True)
+    R.upsample_flow_hip(flow, mask, nd).backward(dev(g["grad_out"]))
+    assert rel(flow.grad, g["d_flow"]) < TOL32
+    assert rel(mask.grad, g["d_mask"]) < TOL32
+    # only the x component (what the model keeps): the y plane gets no gradient
+    flow1, mask1 = dev(g["flow"]).requires_grad_(True), dev(g["mask"]).requires_grad_(True)
+    R.upsample_flow_hip(flow1, mask1, nd, channels=1).backward(dev(g["grad_out"][:, :1]))
+    df, dm = U.upsample_flow_bwd(g["flow"][:, :1], g["mask"], 2 ** nd, g["grad_out"][:, :1])
+    assert rel(flow1.grad[:, :1], df) < TOL32 and float(flow1.grad[:, 1].abs().max()) == 0.0
+    assert rel(mask1.grad, dm) < TOL32
+    # fp16 mask (autocast): gradients rounded where the reference's fp16 tensors round
+    flow2, mask2 = dev(g["flow"]).requires_grad_(True), dev(g["mask"], torch.float16).requires_grad_(True)
+    R.upsample_flow_hip(flow2, mask2, nd).backward(dev(g["grad_out"]))
+    assert mask2.grad.dtype == torch.float16
+    assert rel(flow2.grad, g["d_flow_mask16"]) < TOL16[torch.float16]
+    assert rel(mask2.grad, g["d_mask_mask16"]) < TOL16[torch.float16]
+
+
+def test_upsample_backward_adjoint_identity_at_full_size(R):
+    """<upsample(flow + e), g> - <upsample(flow), g> = <e, d flow> exactly (the map is linear in flow), and the
+    mask gradient sums to zero over the 9 logits of every output pixel (softmax), at the SceneFlow training size."""
+    torch.manual_seed(11)
+    N, H, W, nd = 8, 80, 180, 2
+    f = 4
+    flow = (torch.randn(N, 2, H, W, device="cuda") * 4).requires_grad_(True)
+    mask = torch.randn(N, 9 * f * f, H, W, device="cuda").requires_grad_(True)
+    gout = torch.randn(N, 2, f * H, f * W, device="cuda")
+    up = R.upsample_flow_hip(flow, mask, nd)
+    up.backward(gout)
+    e = torch.randn_like(flow)
+    with torch.no_grad():
+        up2 = R.upsample_flow_hip(flow + e, mask, nd)
+        lhs = ((up2 - up).double() * gout.double()).sum().item()
+        rhs = (e.double() * flow.grad.double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-4 * abs(rhs)
+    s = mask.grad.view(N, 9, f * f, H, W).sum(dim=1).abs().max().item()
+    assert s <= 1e-4 * mask.grad.abs().max().item()
+
+
 @pytest.mark.parametrize("nd,shape", [(2, (8, 96, 312)), (3, (1, 60, 80)), (2, (1, 504, 752))])
 def test_upsample_full_size_properties(R, nd, shape):
     """Size-independent properties at BASELINE sizes: (1) equal logits -> f x the zero-padded 3x3 box mean;
@@ -261,8 +304,6 @@ def test_update_argument_errors(R):
     with pytest.raises(ValueError):
         with torch.no_grad():
             R.upsample_flow_hip(torch.zeros(1, 2, 2, 2).cuda(), torch.zeros(1, 100, 2, 2).cuda(), 2)
-    with pytest.raises(RuntimeError):
-        R.upsample_flow_hip(torch.zeros(1, 2, 2, 2).cuda().requires_grad_(True), torch.zeros(1, 144, 2, 2).cuda(), 2)
     from raft_stereo_amd._lib import lib
     assert lib.rc_upsample_flow_fwd(None, 0, None, None, 1, 1, 1, 1, 4, 0, None) != 0
     assert lib.rc_upsample_flow_fwd(1, 8, 1, 16, 1, 2, 2, 2, 3, 0, None) != 0      # factor 3

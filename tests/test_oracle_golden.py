@@ -193,3 +193,15 @@ def test_upsample_matches_reference(golden, case):
     # fp16 mask (autocast): softmax returns fp16 probabilities
     assert U.rel_to_max(U.upsample_flow(g["flow"], g["mask"].astype(np.float16), f, round_to=np.float16),
                         g["up_mask16"]) <= 2e-3
+
+
+@pytest.mark.parametrize("case", UPSAMPLE_CASES)
+def test_upsample_backward_matches_reference_autograd(golden, case):
+    g = golden(case)
+    f = 2 ** int(g["n_downsample"])
+    df, dm = U.upsample_flow_bwd(g["flow"], g["mask"], f, g["grad_out"])
+    assert U.rel_to_max(df, g["d_flow"]) <= 1e-5
+    assert U.rel_to_max(dm, g["d_mask"]) <= 1e-5
+    df, dm = U.upsample_flow_bwd(g["flow"], g["mask"].astype(np.float16), f, g["grad_out"], round_to=np.float16)
+    assert U.rel_to_max(df, g["d_flow_mask16"]) <= 2e-3
+    assert U.rel_to_max(dm, g["d_mask_mask16"]) <= 2e-3
