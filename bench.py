@@ -220,13 +220,23 @@ def update_ops(cfg, device, n=50):
         t_torch = timed(torch_gru)
         t_up = timed(lambda: R.upsample_flow_hip(flow, mask, nd, channels=1))
         t_up_torch = timed(torch_up)
+    # the adjoints (training): autograd through the library's functions, both flow channels
+    fl, mk = flow.clone().requires_grad_(True), mask.clone().requires_grad_(True)
+    up = R.upsample_flow_hip(fl, mk, nd)
+    gup = torch.randn_like(up)
+    t_up_bwd = timed(lambda: torch.autograd.grad(up, (fl, mk), gup, retain_graph=True))
+    leaves = [t.clone().requires_grad_(True) for t in (zc, qc, h)]
+    hn = R.gru_update(leaves[0], cz, leaves[1], cq, leaves[2])
+    ghn = torch.randn_like(hn)
+    t_upd_bwd = timed(lambda: torch.autograd.grad(hn, leaves, ghn, retain_graph=True))
     el = B * C * H * W
     up_bytes = B * H * W * (9 * f * f * s + 4 + f * f * 4)
     return dict(gru_update_us=round(t_upd, 2), gru_update_gbps=round(6 * el * s / (t_upd * 1e-6) / 1e9, 1),
                 gru_gate_r_us=round(t_gate, 2), gru_gate_r_gbps=round(4 * el * s / (t_gate * 1e-6) / 1e9, 1),
                 gru_pointwise_torch_us=round(t_torch, 2),
                 upsample_us=round(t_up, 2), upsample_gbps=round(up_bytes / (t_up * 1e-6) / 1e9, 1),
-                upsample_torch_us=round(t_up_torch, 2))
+                upsample_torch_us=round(t_up_torch, 2), upsample_bwd_us=round(t_up_bwd, 2),
+                gru_update_bwd_us=round(t_upd_bwd, 2))
 
 
 def hip_graph_step(step, n=50):

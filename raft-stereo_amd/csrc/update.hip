@@ -262,10 +262,10 @@ int launch_gate_r_bwd(const void* convr, const void* cr, int64_t cr_bs, const vo
 }
 
 // ------------------------------------------------------------------------------------- upsampling
-// A wave owns 64 consecutive low-resolution pixels of one row and ONE of the F output rows they
-// expand into (fy); the F waves of a pixel chunk sit next to each other in the grid.  Per group of
-// G = min(F,4) output columns (fx) the lane loads its 9 G mask logits (every load of the wave is one
-// contiguous run of a mask plane), normalises them and writes G consecutive output pixels per flow
+// A wave owns 64 consecutive low-resolution pixels of one row and walks the F x F output pixels each
+// expands into, G = min(F,4) output columns (fx) of one output row (fy) per step: the lane loads its
+// 9 G mask logits (every load of the wave is one contiguous run of a mask plane; the next step's loads are
+// issued before this step's arithmetic), normalises them and writes G consecutive output pixels per flow
 // channel as one 8/16-byte store: the wave's store is one contiguous run of an output row.
 // MT is the mask type: softmax evaluates in fp32 and rounds to MT, as torch.softmax on an MT tensor
 // does (core/raft_stereo.py:60; the mask is fp16 under autocast), the products and the sum are fp32.
@@ -284,19 +284,30 @@ template <typename MT, int F, int C>
 __global__ __launch_bounds__(PW_THREADS) void upsample_kernel(const float* __restrict__ flow, int64_t flow_bs,
                                                               const MT* __restrict__ mask, float* __restrict__ out,
                                                               int H, int W, int chunks_per_row, int n_items) {
-  constexpr int G = F < 4 ? F : 4;
+  constexpr int G = F < 4 ? F : 4;    // output columns per step
+  constexpr int S = F * (F / G);      // steps: (fy, column group) pairs
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int item = blockIdx.x * (PW_THREADS / 64) + wave;  // ((n*H + h)*chunks + chunk)*F + fy, wave-uniform
+  const int item = blockIdx.x * (PW_THREADS / 64) + wave;  // (n*H + h)*chunks + chunk, wave-uniform
   if (item >= n_items) return;
-  const int fy = item % F;
-  const int t = item / F;
-  const int nh = t / chunks_per_row;
-  const int c0 = (t - nh * chunks_per_row) * 64;
+  const int nh = item / chunks_per_row;
+  const int c0 = (item - nh * chunks_per_row) * 64;
   const int n = nh / H, h = nh - n * H;
   const int w = c0 + lane;
   if (w >= W) return;
   const int64_t HW = (int64_t)H * W;
+
+  // mask[n, k, fy, fx, h, w]: plane (k*F + fy)*F + fx of image n.  Step s covers planes k*F*F + s*G + j.
+  const MT* mrow = mask + up_uniform((int64_t)n * 9 * F * F * HW + (int64_t)h * W + c0);
+  const uint32_t HWu = (uint32_t)HW;
+  MT buf[2][9][G];  // the next step's logits are in flight while this step's are normalised
+  auto fetch = [&](int s, MT (&m)[9][G]) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+      for (int j = 0; j < G; ++j) m[k][j] = mrow[(uint32_t)(k * F * F + s * G + j) * HWu + (uint32_t)lane];
+  };
+  fetch(0, buf[0]);
 
   // factor * flow at the 9 neighbours (F.unfold(factor*flow, [3,3], padding=1): zeros outside)
   float v[C][9];
@@ -317,31 +328,27 @@ __global__ __launch_bounds__(PW_THREADS) void upsample_kernel(const float* __res
     }
   }
 
-  // mask[n, k, fy, fx, h, w]: plane (k*F + fy)*F + fx of image n
-  const MT* mrow = mask + up_uniform(((int64_t)n * 9 * F * F + (int64_t)fy * F) * HW + (int64_t)h * W + c0);
-  float* orow = out + up_uniform((((int64_t)n * C * H + h) * F + fy) * (int64_t)F * W + (int64_t)F * c0);
-  const uint32_t HWu = (uint32_t)HW;
+  float* orow = out + up_uniform(((int64_t)n * C * H + h) * F * (int64_t)F * W + (int64_t)F * c0);
+  constexpr float LOG2E = 1.4426950408889634f;
 #pragma unroll
-  for (int g0 = 0; g0 < F; g0 += G) {
-    float m[9][G];
-#pragma unroll
-    for (int k = 0; k < 9; ++k)
-#pragma unroll
-      for (int j = 0; j < G; ++j) m[k][j] = rc_to_float(mrow[(uint32_t)(k * F * F + g0 + j) * HWu + (uint32_t)lane]);
+  for (int s = 0; s < S; ++s) {
+    if (s + 1 < S) fetch(s + 1, buf[(s + 1) & 1]);
+    const MT(&m)[9][G] = buf[s & 1];
+    const int fy = s / (F / G), g0 = (s % (F / G)) * G;
     float res[C][G];
 #pragma unroll
     for (int j = 0; j < G; ++j) {
-      float mx = m[0][j];
+      float mx = rc_to_float(m[0][j]);
 #pragma unroll
-      for (int k = 1; k < 9; ++k) mx = fmaxf(mx, m[k][j]);
-      float e[9], s = 0.f;
+      for (int k = 1; k < 9; ++k) mx = fmaxf(mx, rc_to_float(m[k][j]));
+      float e[9], sum = 0.f;
 #pragma unroll
       for (int k = 0; k < 9; ++k) {
         if constexpr (sizeof(MT) == 4) e[k] = expf(m[k][j] - mx);
-        else e[k] = __expf(m[k][j] - mx);
-        s += e[k];
+        else e[k] = __builtin_amdgcn_exp2f(fmaf(rc_to_float(m[k][j]), LOG2E, -mx * LOG2E));
+        sum += e[k];
       }
-      const float inv = sizeof(MT) == 4 ? 1.0f / s : __builtin_amdgcn_rcpf(s);
+      const float inv = sizeof(MT) == 4 ? 1.0f / sum : __builtin_amdgcn_rcpf(sum);
 #pragma unroll
       for (int c = 0; c < C; ++c) res[c][j] = 0.f;
 #pragma unroll
@@ -360,8 +367,8 @@ __global__ __launch_bounds__(PW_THREADS) void upsample_kernel(const float* __res
 #pragma unroll
         for (int j = 0; j < G; ++j) o[j] = res[c][j];
       }
-      float* dst = orow + up_uniform((int64_t)c * H * F * F * W) + (uint32_t)(lane * F + g0);
-      *reinterpret_cast<typename up_vec<G>::type*>(dst) = o;
+      float* dst = orow + up_uniform(((int64_t)c * H * F + fy) * (int64_t)F * W) + (uint32_t)(lane * F + g0);
+      __builtin_nontemporal_store(o, reinterpret_cast<typename up_vec<G>::type*>(dst));
     }
   }
 }
@@ -415,8 +422,9 @@ __global__ __launch_bounds__(PW_THREADS) void upsample_bwd_kernel(const float* _
   MT* drow = dmask + mbase;
   const float* grow = gout + up_uniform(((int64_t)n * C * H + h) * F * (int64_t)F * W + (int64_t)F * c0);
   const uint32_t HWu = (uint32_t)HW;
+#pragma unroll 1
   for (int fy = 0; fy < F; ++fy) {
-#pragma unroll
+#pragma unroll 1
     for (int g0 = 0; g0 < F; g0 += G) {
       float m[9][G];
       const uint32_t pl0 = (uint32_t)(fy * F + g0);
@@ -543,7 +551,7 @@ template <typename MT, int F, int C>
 int launch_upsample(const float* flow, int64_t flow_bs, const void* mask, float* out, int64_t N, int64_t H,
                     int64_t W, hipStream_t st) {
   const int chunks = (int)((W + 63) / 64);
-  const int64_t items = N * H * chunks * F;
+  const int64_t items = N * H * chunks;
   RC_REQUIRE(items < (1ll << 31), RC_EINVAL, "too many pixels");
   const int blocks = (int)((items + PW_THREADS / 64 - 1) / (PW_THREADS / 64));
   hipLaunchKernelGGL((upsample_kernel<MT, F, C>), blocks, dim3(PW_THREADS), 0, st, flow, flow_bs,
