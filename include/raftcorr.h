@@ -286,6 +286,34 @@ int rc_upsample_flow_bwd(const float* flow, int64_t flow_batch_stride, const voi
                          int64_t grad_flow_batch_stride, void* work, int64_t N, int channels,
                          int64_t H, int64_t W, int factor, int mask_dtype, void* stream);
 
+/*
+ * SURVEY.md section 8(f) rank 4, second half -- sequence_loss (train_stereo.py:35-70) over all n GRU
+ * iterations' predictions in one pass (the reference runs ~8 tensor ops and a boolean-mask gather, i.e. a
+ * host synchronisation, per prediction):
+ *     valid' = (valid >= 0.5) & (|flow_gt| < max_flow)
+ *     loss   = sum_i weights[i] * mean over valid' of |pred_i - flow_gt|        weights[i] = gamma'^(n-i-1)
+ *     epe    = |pred_last - flow_gt| on valid'
+ * preds: HOST array of n (<= RC_MAX_FUSED_LOOKUPS) device pointers, each float [N,1,H,W] whose images are
+ * pred_batch_stride elements apart (flow_up[:, :1] of a 2-channel tensor is fine); weights: HOST float[n];
+ * flow_gt float [N,1,H,W], valid float [N,H,W], HW = H*W.  results: DEVICE double[n+7] =
+ *     [0,n) sum_i, [n] #valid', [n+1] sum epe, [n+2..n+4] #epe<1, <3, <5, [n+5] loss, [n+6] number of
+ *     non-finite prediction values (the reference asserts there are none, train_stereo.py:51-52).
+ * Block partials (float) go to `work` (rc_sequence_loss_work_bytes) and are added in double in a fixed order:
+ * no atomics, reproducible run to run.  rc_sequence_loss_bwd writes
+ *     grad_preds[i] = grad_loss[0] * weights[i] * sign(pred_i - flow_gt) / #valid'  on valid', 0 elsewhere,
+ * reading #valid' from `results` and the upstream gradient from the DEVICE scalar grad_loss (no host sync).
+ */
+int64_t rc_sequence_loss_work_bytes(int n_predictions);
+int rc_sequence_loss_fwd(const float* const* preds, const float* weights, int n_predictions,
+                         int64_t pred_batch_stride, const float* flow_gt, const float* valid,
+                         float max_flow, double* results, void* work, int64_t N, int64_t HW,
+                         void* stream);
+int rc_sequence_loss_bwd(const float* const* preds, float* const* grad_preds, const float* weights,
+                         int n_predictions, int64_t pred_batch_stride, int64_t grad_batch_stride,
+                         const float* flow_gt, const float* valid, float max_flow,
+                         const double* results, const float* grad_loss, int64_t N, int64_t HW,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,10 +13,12 @@ tree, which is NOT shipped):
   gru_gate_r_bwd    autograd of the same lines
   upsample_flow     core/raft_stereo.py:55-67 softmax over 9, unfold(factor*flow, 3x3, padding=1), sum, permute
   upsample_flow_bwd autograd of the same lines
+  sequence_loss     train_stereo.py:35-70     masked L1 over all predictions, EPE metrics, and its gradient
 
 Parity pin: tests/test_oracle_golden.py checks these against vectors captured from the reference's own
 Python (tests/golden/make_golden_update.py ran `core.update.ConvGRU` and `RAFTStereo.upsample_flow` on
-CPU in the build container and recorded the convolution outputs next to the results).  The reference
+CPU in the build container and recorded the convolution outputs next to the results; make_golden_loss.py
+ran the reference's `sequence_loss` function).  The reference
 has no tests or fixtures of its own for these lines.
 """
 import numpy as np
@@ -122,6 +124,30 @@ def upsample_flow_bwd(flow, mask, factor, grad_out, round_to=None):
     gp = rd(gp.astype(F32)).astype(np.float64)
     dmask = rd((p * (gp - (p * gp).sum(axis=1, keepdims=True))).astype(F32)).reshape(N, 9 * f * f, H, W)
     return (f * dpad[:, :, 1:-1, 1:-1]).astype(F32), dmask
+
+
+def sequence_loss(flow_preds, flow_gt, valid, loss_gamma=0.9, max_flow=700):
+    """(loss, metrics, grads) of train_stereo.py:35-70 for one flow channel.
+
+    valid' = (valid >= 0.5) & (|gt| < max_flow); loss = sum_i gamma'^(n-i-1) * mean_valid' |pred_i - gt| with
+    gamma' = gamma^(15/(n-1)); epe = |pred_last - gt| on valid' -> mean, fraction < 1, < 3, < 5; the gradient
+    of the loss w.r.t. pred_i is w_i * sign(pred_i - gt) / #valid' on valid'."""
+    n = len(flow_preds)
+    gt = np.asarray(flow_gt, dtype=F32)
+    mag = np.sqrt(np.sum(gt.astype(F32) ** 2, axis=1))
+    ok = ((np.asarray(valid, F32) >= 0.5) & (mag < max_flow))[:, None]
+    cnt = int(ok.sum())
+    g = loss_gamma ** (15 / (n - 1))
+    loss, grads = 0.0, []
+    for i, p in enumerate(flow_preds):
+        w = g ** (n - i - 1)
+        d = np.asarray(p, F32) - gt
+        loss += w * float(np.abs(d)[ok].astype(np.float64).mean())
+        grads.append(np.where(ok, w * np.sign(d) / cnt, 0.0).astype(F32))
+    epe = np.sqrt(np.sum((np.asarray(flow_preds[-1], F32) - gt) ** 2, axis=1))[ok[:, 0]].astype(np.float64)
+    metrics = {"epe": float(epe.mean()), "1px": float((epe < 1).mean()), "3px": float((epe < 3).mean()),
+               "5px": float((epe < 5).mean())}
+    return loss, metrics, grads
 
 
 def rel_to_max(a, b):

@@ -72,6 +72,10 @@ SIGNATURES = {
     "rc_upsample_flow_fwd": (_I, [_P, _L, _P, _P, _L, _I, _L, _L, _I, _I, _P]),
     "rc_upsample_flow_bwd_work_bytes": (_L, [_L, _I, _L, _L]),
     "rc_upsample_flow_bwd": (_I, [_P, _L, _P, _P, _P, _P, _L, _P, _L, _I, _L, _L, _I, _I, _P]),
+    "rc_sequence_loss_work_bytes": (_L, [_I]),
+    "rc_sequence_loss_fwd": (_I, [C.POINTER(_P), C.POINTER(C.c_float), _I, _L, _P, _P, C.c_float, _P, _P, _L, _L, _P]),
+    "rc_sequence_loss_bwd": (_I, [C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_float), _I, _L, _L, _P, _P,
+                                  C.c_float, _P, _P, _L, _L, _P]),
 }
 
 

@@ -699,3 +699,222 @@ extern "C" int rc_upsample_flow_bwd(const float* flow, int64_t flow_batch_stride
   rc_set_error("unknown mask dtype %d", mask_dtype);
   return RC_EUNSUPPORTED;
 }
+
+// ---------------------------------------------------------------------------------- sequence loss
+// train_stereo.py:35-70 (sequence_loss): one pass over all n predictions instead of ~8 torch ops and a
+// boolean-mask gather (a host synchronisation) per prediction.
+//   valid' = (valid >= 0.5) & (|flow_gt| < max_flow)            (one flow channel: stereo)
+//   loss   = sum_i w_i * mean over valid' of |pred_i - flow_gt|
+//   epe    = |pred_last - flow_gt| over valid':  mean, fraction < 1, < 3, < 5
+// Kernel 1: grid (pixel blocks, chunks of SL_P predictions); a block strides over pixels and reduces its
+// SL_P sums (and, in the chunks that own them, the pixel count and the metrics of the last prediction) to
+// one float partial each.  Kernel 2: one wave per quantity adds the partials in double in a fixed order
+// (reproducible run to run), then the loss is formed.  results (double):
+//   [0,n) sum_i |pred_i - gt|, [n] count, [n+1] sum epe, [n+2..n+4] #epe<1,<3,<5, [n+5] loss, [n+6] non-finite
+//   values seen in the predictions (the reference asserts there are none, train_stereo.py:51-52)
+namespace {
+
+constexpr int SL_P = 8;            // predictions per block
+constexpr int SL_MAX_BLOCKS = 512; // pixel blocks (partials per quantity)
+constexpr int SL_EXTRA = 5;        // count, epe sum, <1, <3, <5
+
+struct sl_ptrs {
+  const float* pred[RC_MAX_FUSED_LOOKUPS];
+  float* grad[RC_MAX_FUSED_LOOKUPS];
+  float weight[RC_MAX_FUSED_LOOKUPS];
+};
+
+__device__ __forceinline__ float sl_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// sum over the block's 4 waves; the result is valid in thread 0
+__device__ __forceinline__ float sl_block_sum(float v, float* red) {
+  v = sl_wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(PW_THREADS) void seqloss_partial_kernel(sl_ptrs ptrs, int n, int64_t pred_bs,
+                                                                     const float* __restrict__ gt,
+                                                                     const float* __restrict__ valid, float max_flow,
+                                                                     float* __restrict__ partial, int64_t HW,
+                                                                     int64_t total) {
+  __shared__ float red[4];
+  const int chunk = blockIdx.y, i0 = chunk * SL_P;
+  const int nblk = gridDim.x;
+  float acc[SL_P], cnt = 0.f, epe = 0.f, n1 = 0.f, n3 = 0.f, n5 = 0.f, bad = 0.f;
+#pragma unroll
+  for (int j = 0; j < SL_P; ++j) acc[j] = 0.f;
+  const int jlast = n - 1 - i0;  // slot of the last prediction, if this chunk holds it
+  for (int64_t p = (int64_t)blockIdx.x * PW_THREADS + threadIdx.x; p < total; p += (int64_t)nblk * PW_THREADS) {
+    const int64_t b = p / HW, q = p - b * HW;
+    const float g = gt[p], va = valid[p];
+    const bool ok = (va >= 0.5f) && (sqrtf(g * g) < max_flow);
+    cnt += ok ? 1.f : 0.f;
+#pragma unroll
+    for (int j = 0; j < SL_P; ++j) {
+      const int i = min(i0 + j, n - 1);  // past the end: re-read the last one, not accumulated
+      const float x = ptrs.pred[i][b * pred_bs + q];
+      const float d = fabsf(x - g);
+      if (i0 + j < n) {
+        acc[j] += ok ? d : 0.f;
+        bad += (fabsf(x) <= 3.0e38f) ? 0.f : 1.f;  // false for inf and nan
+        if (j == jlast && ok) {
+          const float e = sqrtf((x - g) * (x - g));
+          epe += e;
+          n1 += e < 1.f ? 1.f : 0.f;
+          n3 += e < 3.f ? 1.f : 0.f;
+          n5 += e < 5.f ? 1.f : 0.f;
+        }
+      }
+    }
+  }
+  // partial[q][block]: quantity q of this pixel block
+  const int nq = n + SL_EXTRA + gridDim.y;
+#pragma unroll
+  for (int j = 0; j < SL_P; ++j) {
+    const float s = sl_block_sum(acc[j], red);
+    if (threadIdx.x == 0 && i0 + j < n) partial[(int64_t)(i0 + j) * nblk + blockIdx.x] = s;
+  }
+  if (chunk == 0) {
+    const float s = sl_block_sum(cnt, red);
+    if (threadIdx.x == 0) partial[(int64_t)n * nblk + blockIdx.x] = s;
+  }
+  if (jlast >= 0 && jlast < SL_P) {
+    const float s0 = sl_block_sum(epe, red), s1 = sl_block_sum(n1, red), s3 = sl_block_sum(n3, red),
+                s5 = sl_block_sum(n5, red);
+    if (threadIdx.x == 0) {
+      partial[(int64_t)(n + 1) * nblk + blockIdx.x] = s0;
+      partial[(int64_t)(n + 2) * nblk + blockIdx.x] = s1;
+      partial[(int64_t)(n + 3) * nblk + blockIdx.x] = s3;
+      partial[(int64_t)(n + 4) * nblk + blockIdx.x] = s5;
+    }
+  }
+  {
+    const float s = sl_block_sum(bad, red);
+    if (threadIdx.x == 0) partial[(int64_t)(n + SL_EXTRA + chunk) * nblk + blockIdx.x] = s;
+  }
+  (void)nq;
+}
+
+__global__ __launch_bounds__(1024) void seqloss_final_kernel(const float* __restrict__ partial, int nblk, int n,
+                                                             int nchunks, sl_ptrs ptrs, double* __restrict__ results) {
+  __shared__ double q[RC_MAX_FUSED_LOOKUPS + SL_EXTRA + RC_MAX_FUSED_LOOKUPS / SL_P + 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int nq = n + SL_EXTRA + nchunks;
+  for (int k = wave; k < nq; k += nw) {
+    double s = 0.0;
+    for (int t = lane; t < nblk; t += 64) s += (double)partial[(int64_t)k * nblk + t];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) q[k] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double loss = 0.0, bad = 0.0;
+    for (int i = 0; i < n; ++i) {
+      results[i] = q[i];
+      loss += (double)ptrs.weight[i] * (q[i] / q[n]);  // mean over the valid pixels; 0/0 = nan like torch's empty mean
+    }
+    for (int k = 0; k < SL_EXTRA; ++k) results[n + k] = q[n + k];
+    for (int c = 0; c < nchunks; ++c) bad += q[n + SL_EXTRA + c];
+    results[n + 5] = loss;
+    results[n + 6] = bad;
+  }
+}
+
+// d loss / d pred_i = grad_loss * w_i * sign(pred_i - gt) / count on valid' pixels, 0 elsewhere
+__global__ __launch_bounds__(PW_THREADS) void seqloss_bwd_kernel(sl_ptrs ptrs, int n, int64_t pred_bs, int64_t grad_bs,
+                                                                 const float* __restrict__ gt,
+                                                                 const float* __restrict__ valid, float max_flow,
+                                                                 const double* __restrict__ results,
+                                                                 const float* __restrict__ grad_loss, int64_t HW,
+                                                                 int64_t total) {
+  const int64_t p = (int64_t)blockIdx.x * PW_THREADS + threadIdx.x;
+  if (p >= total) return;
+  const int64_t b = p / HW, q = p - b * HW;
+  const float g = gt[p], va = valid[p];
+  const bool ok = (va >= 0.5f) && (sqrtf(g * g) < max_flow);
+  const float scale = grad_loss[0] / (float)results[n];
+  for (int i = 0; i < n; ++i) {  // i is uniform: pointers and weights come through scalar loads
+    const float x = ptrs.pred[i][b * pred_bs + q];
+    const float d = x - g;
+    const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    ptrs.grad[i][b * grad_bs + q] = ok ? scale * ptrs.weight[i] * sgn : 0.f;
+  }
+}
+
+inline int sl_blocks(int64_t total) {
+  const int64_t nb = (total + PW_THREADS - 1) / PW_THREADS;
+  return (int)(nb < SL_MAX_BLOCKS ? nb : SL_MAX_BLOCKS);
+}
+
+}  // namespace
+
+extern "C" int64_t rc_sequence_loss_work_bytes(int n_predictions) {
+  if (n_predictions < 1 || n_predictions > RC_MAX_FUSED_LOOKUPS) return -1;
+  const int nchunks = (n_predictions + SL_P - 1) / SL_P;
+  return (int64_t)(n_predictions + SL_EXTRA + nchunks) * SL_MAX_BLOCKS * (int64_t)sizeof(float);
+}
+
+extern "C" int rc_sequence_loss_fwd(const float* const* preds, const float* weights, int n_predictions,
+                                    int64_t pred_batch_stride, const float* flow_gt, const float* valid,
+                                    float max_flow, double* results, void* work, int64_t N, int64_t HW,
+                                    void* stream) {
+  RC_REQUIRE(preds && weights && flow_gt && valid && results && work, RC_EINVAL, "null pointer argument");
+  RC_REQUIRE(n_predictions >= 1 && n_predictions <= RC_MAX_FUSED_LOOKUPS, RC_EUNSUPPORTED,
+             "n_predictions %d outside 1..%d", n_predictions, RC_MAX_FUSED_LOOKUPS);
+  RC_REQUIRE(N > 0 && HW > 0 && N * HW < (1ll << 40) && pred_batch_stride >= HW, RC_EINVAL,
+             "bad sizes N=%lld HW=%lld stride=%lld", (long long)N, (long long)HW, (long long)pred_batch_stride);
+  sl_ptrs ptrs;
+  for (int i = 0; i < RC_MAX_FUSED_LOOKUPS; ++i) {
+    const int s = i < n_predictions ? i : 0;
+    RC_REQUIRE(preds[s], RC_EINVAL, "null pointer in the prediction list");
+    ptrs.pred[i] = preds[s];
+    ptrs.grad[i] = nullptr;
+    ptrs.weight[i] = i < n_predictions ? weights[i] : 0.f;
+  }
+  const int64_t total = N * HW;
+  const int nblk = sl_blocks(total), nchunks = (n_predictions + SL_P - 1) / SL_P;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(seqloss_partial_kernel, dim3(nblk, nchunks), dim3(PW_THREADS), 0, st, ptrs, n_predictions,
+                     pred_batch_stride, flow_gt, valid, max_flow, (float*)work, HW, total);
+  int rc = rc_check_launch("rc_sequence_loss_fwd");
+  if (rc) return rc;
+  hipLaunchKernelGGL(seqloss_final_kernel, dim3(1), dim3(1024), 0, st, (const float*)work, nblk, n_predictions,
+                     nchunks, ptrs, results);
+  return rc_check_launch("rc_sequence_loss_fwd(final)");
+}
+
+extern "C" int rc_sequence_loss_bwd(const float* const* preds, float* const* grad_preds, const float* weights,
+                                    int n_predictions, int64_t pred_batch_stride, int64_t grad_batch_stride,
+                                    const float* flow_gt, const float* valid, float max_flow, const double* results,
+                                    const float* grad_loss, int64_t N, int64_t HW, void* stream) {
+  RC_REQUIRE(preds && grad_preds && weights && flow_gt && valid && results && grad_loss, RC_EINVAL,
+             "null pointer argument");
+  RC_REQUIRE(n_predictions >= 1 && n_predictions <= RC_MAX_FUSED_LOOKUPS, RC_EUNSUPPORTED,
+             "n_predictions %d outside 1..%d", n_predictions, RC_MAX_FUSED_LOOKUPS);
+  RC_REQUIRE(N > 0 && HW > 0 && N * HW < (1ll << 40) && pred_batch_stride >= HW && grad_batch_stride >= HW, RC_EINVAL,
+             "bad sizes N=%lld HW=%lld", (long long)N, (long long)HW);
+  sl_ptrs ptrs;
+  for (int i = 0; i < RC_MAX_FUSED_LOOKUPS; ++i) {
+    const int s = i < n_predictions ? i : 0;
+    RC_REQUIRE(preds[s] && grad_preds[s], RC_EINVAL, "null pointer in the prediction lists");
+    ptrs.pred[i] = preds[s];
+    ptrs.grad[i] = grad_preds[s];
+    ptrs.weight[i] = i < n_predictions ? weights[i] : 0.f;
+  }
+  const int64_t total = N * HW;
+  const int64_t nb = (total + PW_THREADS - 1) / PW_THREADS;
+  RC_REQUIRE(nb < (1ll << 31), RC_EINVAL, "too many pixels");
+  hipLaunchKernelGGL(seqloss_bwd_kernel, dim3((unsigned)nb), dim3(PW_THREADS), 0, (hipStream_t)stream, ptrs,
+                     n_predictions, pred_batch_stride, grad_batch_stride, flow_gt, valid, max_flow, results, grad_loss,
+                     HW, total);
+  return rc_check_launch("rc_sequence_loss_bwd");
+}

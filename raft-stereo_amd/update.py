@@ -4,11 +4,14 @@
     ConvGRUHip(hidden_dim, input_dim, kernel_size=3)      core/update.py:16-32  ConvGRU
         .forward(h, cz, cr, cq, *x_list)                  same parameters (convz/convr/convq), same call
     upsample_flow_hip(flow, mask, n_downsample)           core/raft_stereo.py:55-67  RAFTStereo.upsample_flow
+    sequence_loss_hip(flow_preds, flow_gt, valid, ...)    train_stereo.py:35-70      sequence_loss
 
 The three convolutions of the GRU are torch's (dense convolutions are outside this package's path); the
 sigmoid / tanh / blend arithmetic around them and the whole convex upsampling run in the HIP library.
 There is no CPU or eager fallback: tensors must live on a GPU.
 """
+import ctypes
+
 import torch
 import torch.nn as nn
 
@@ -212,3 +215,89 @@ def upsample_flow_hip(flow, mask, n_downsample, channels=None):
     if mask.dtype not in _DT:
         raise TypeError(f"unsupported mask dtype {mask.dtype}")
     return _UpsampleFn.apply(flow.float().contiguous(), mask.contiguous(), f, C)
+
+
+def _pred_view(p, N, H, W):
+    """A prediction as (tensor, batch stride): float [N,1,H,W] whose images are dense (a `[:, :1]` slice of a
+    2-channel tensor qualifies); anything else is copied."""
+    if p.dtype is not torch.float32 or p.stride()[2:] != (W, 1) or (N > 1 and p.stride(0) < H * W):
+        p = p.float().contiguous()
+    return p, (p.stride(0) if N > 1 else H * W)
+
+
+class _SeqLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, flow_gt, valid, max_flow, weights, *preds):
+        n = len(preds)
+        N, _, H, W = flow_gt.shape
+        dev = flow_gt.device
+        views = [_pred_view(p, N, H, W) for p in preds]
+        bs = views[0][1]
+        if any(v[1] != bs for v in views):
+            views = [(v[0].contiguous(), H * W) for v in views]
+            bs = H * W
+        ptrs = (ctypes.c_void_p * n)(*[v[0].data_ptr() for v in views])
+        wts = (ctypes.c_float * n)(*weights)
+        with _on_device(dev):
+            results = torch.empty(n + 7, dtype=torch.float64, device=dev)
+            work = torch.empty(int(lib.rc_sequence_loss_work_bytes(n)), dtype=torch.uint8, device=dev)
+            check(lib.rc_sequence_loss_fwd(ptrs, wts, n, bs, flow_gt.data_ptr(), valid.data_ptr(), float(max_flow),
+                                           results.data_ptr(), work.data_ptr(), N, H * W, _stream(dev)),
+                  "rc_sequence_loss_fwd")
+        ctx.views, ctx.bs, ctx.weights, ctx.max_flow = [v[0] for v in views], bs, weights, float(max_flow)
+        ctx.save_for_backward(flow_gt, valid, results)
+        ctx.mark_non_differentiable(results)
+        return results[n + 5].float(), results
+
+    @staticmethod
+    def backward(ctx, grad_loss, _grad_results):
+        flow_gt, valid, results = ctx.saved_tensors
+        n = len(ctx.views)
+        N, _, H, W = flow_gt.shape
+        dev = flow_gt.device
+        grads = [torch.empty((N, 1, H, W), dtype=torch.float32, device=dev) for _ in range(n)]
+        ptrs = (ctypes.c_void_p * n)(*[v.data_ptr() for v in ctx.views])
+        gptrs = (ctypes.c_void_p * n)(*[g.data_ptr() for g in grads])
+        wts = (ctypes.c_float * n)(*ctx.weights)
+        gl = grad_loss.float().contiguous()
+        with _on_device(dev):
+            check(lib.rc_sequence_loss_bwd(ptrs, gptrs, wts, n, ctx.bs, H * W, flow_gt.data_ptr(), valid.data_ptr(),
+                                           ctx.max_flow, results.data_ptr(), gl.data_ptr(), N, H * W, _stream(dev)),
+                  "rc_sequence_loss_bwd")
+        return (None, None, None, None, *grads)
+
+
+def sequence_loss_hip(flow_preds, flow_gt, valid, loss_gamma=0.9, max_flow=700):
+    """sequence_loss of the reference (train_stereo.py:35-70): `(flow_loss, metrics)` from the list of
+    per-iteration predictions `[N,1,H,W]`, the ground truth `[N,1,H,W]` and the validity map `[N,H,W]`.
+    One pass over all predictions on the GPU and ONE host synchronisation (for the metrics' `.item()`s, which
+    the reference also pays, on top of one per prediction for its boolean-mask gathers).  The reference's
+    asserts (no nan/inf in the predictions, train_stereo.py:51-52) are checked on the same synchronisation."""
+    n_predictions = len(flow_preds)
+    assert n_predictions >= 1
+    if n_predictions > _lib.RC_MAX_FUSED_LOOKUPS:
+        raise ValueError(f"at most {_lib.RC_MAX_FUSED_LOOKUPS} predictions per call")
+    if not (flow_gt.is_cuda and valid.is_cuda and all(p.is_cuda for p in flow_preds)):
+        raise RuntimeError("sequence_loss_hip needs GPU tensors (there is no CPU path)")
+    if flow_gt.dim() != 4 or flow_gt.shape[1] != 1:
+        raise ValueError("flow_gt must be [N,1,H,W] (stereo: one flow channel)")
+    N, _, H, W = flow_gt.shape
+    assert valid.unsqueeze(1).shape == flow_gt.shape, [valid.shape, flow_gt.shape]       # train_stereo.py:47
+    for p in flow_preds:
+        assert p.shape == flow_gt.shape, [p.shape, flow_gt.shape]                        # train_stereo.py:57
+    # We adjust the loss_gamma so it is consistent for any number of iterations (train_stereo.py:53-55)
+    adjusted_loss_gamma = loss_gamma ** (15 / (n_predictions - 1))
+    weights = [adjusted_loss_gamma ** (n_predictions - i - 1) for i in range(n_predictions)]
+    flow_loss, results = _SeqLossFn.apply(flow_gt.detach().float().contiguous(), valid.detach().float().contiguous(),
+                                          max_flow, weights, *flow_preds)
+    r = results.tolist()                       # the one synchronisation
+    n = n_predictions
+    assert r[n + 6] == 0, "nan or inf in the flow predictions"                           # train_stereo.py:51-52
+    cnt = r[n]
+    metrics = {
+        'epe': r[n + 1] / cnt if cnt else float("nan"),
+        '1px': r[n + 2] / cnt if cnt else float("nan"),
+        '3px': r[n + 3] / cnt if cnt else float("nan"),
+        '5px': r[n + 4] / cnt if cnt else float("nan"),
+    }
+    return flow_loss, metrics

@@ -17,6 +17,8 @@ CONVC1_CASES = [n[len("convc1_"):] for n in _NPZ if n.startswith("convc1_")]
 # the reference's ConvGRU and upsample_flow (make_golden_update.py)
 GRU_CASES = [n for n in _NPZ if n.startswith("update_gru_")]
 UPSAMPLE_CASES = [n for n in _NPZ if n.startswith("update_up_")]
+# the reference's sequence_loss (make_golden_loss.py)
+LOSS_CASES = [n for n in _NPZ if n.startswith("update_loss_")]
 
 
 def pytest_configure(config):

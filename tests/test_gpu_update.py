@@ -14,7 +14,7 @@ import pytest
 import torch
 
 from oracle import update_oracle as U
-from conftest import GRU_CASES, UPSAMPLE_CASES
+from conftest import GRU_CASES, LOSS_CASES, UPSAMPLE_CASES
 
 pytestmark = pytest.mark.gpu
 
@@ -290,6 +290,50 @@ def test_upsample_full_size_properties(R, nd, shape):
         centre[:, 4] = 0
         upk = R.upsample_flow_hip(flow, centre.view(N, 9 * f * f, H, W), nd)
         assert torch.equal(upk, (f * flow).repeat_interleave(f, dim=2).repeat_interleave(f, dim=3))
+
+
+# ------------------------------------------------------------------ sequence loss
+@pytest.mark.parametrize("case", LOSS_CASES)
+def test_sequence_loss_matches_reference(R, golden, case):
+    g = golden(case)
+    n = int(g["n"])
+    preds = [dev(g[f"pred_{i}"]).requires_grad_(True) for i in range(n)]
+    loss, metrics = R.sequence_loss_hip(preds, dev(g["gt"]), dev(g["valid"]), loss_gamma=float(g["gamma"]),
+                                        max_flow=float(g["max_flow"]))
+    assert loss.dtype == torch.float32 and loss.dim() == 0
+    assert abs(loss.item() - float(g["loss"])) <= TOL32 * abs(float(g["loss"]))
+    for k, m in enumerate(("epe", "1px", "3px", "5px")):
+        assert abs(metrics[m] - float(g["metrics"][k])) <= 1e-5
+    (2.0 * loss).backward()                      # an upstream gradient other than 1
+    for i in range(n):
+        assert rel(preds[i].grad, 2.0 * g[f"d_pred_{i}"]) < TOL32, i
+
+
+def test_sequence_loss_on_channel_slices_and_full_size(R):
+    """Predictions handed over as `flow_up[:, :1]` slices of 2-channel tensors (core/raft_stereo.py:134) at the
+    SceneFlow training size (8 x 320 x 720, 22 predictions), against the oracle; deterministic run to run."""
+    torch.manual_seed(21)
+    N, H, W, n = 8, 320, 720, 22
+    gt = -torch.rand(N, 1, H, W, device="cuda") * 100
+    valid = (torch.rand(N, H, W, device="cuda") > 0.1).float()
+    full = [(gt + torch.randn(N, 2, H, W, device="cuda") * 3).requires_grad_(True) for _ in range(n)]
+    preds = [f[:, :1] for f in full]
+    loss, metrics = R.sequence_loss_hip(preds, gt, valid)
+    loss.backward()
+    ref_loss, ref_metrics, ref_grads = U.sequence_loss([p.detach().cpu().numpy() for p in preds], gt.cpu().numpy(),
+                                                       valid.cpu().numpy())
+    assert abs(loss.item() - ref_loss) <= TOL32 * abs(ref_loss)
+    for m in ref_metrics:
+        assert abs(metrics[m] - ref_metrics[m]) <= 1e-5
+    for i in (0, 7, n - 1):
+        assert rel(full[i].grad[:, :1], ref_grads[i]) < TOL32
+        assert float(full[i].grad[:, 1].abs().max()) == 0.0
+    loss2, _ = R.sequence_loss_hip([p.detach() for p in preds], gt, valid)
+    assert loss2.item() == loss.item()
+    with pytest.raises(AssertionError):          # train_stereo.py:51-52
+        bad = [p.detach().clone() for p in preds]
+        bad[3][0, 0, 5, 5] = float("nan")
+        R.sequence_loss_hip(bad, gt, valid)
 
 
 def test_update_argument_errors(R):

@@ -205,3 +205,19 @@ def test_upsample_backward_matches_reference_autograd(golden, case):
     df, dm = U.upsample_flow_bwd(g["flow"], g["mask"].astype(np.float16), f, g["grad_out"], round_to=np.float16)
     assert U.rel_to_max(df, g["d_flow_mask16"]) <= 2e-3
     assert U.rel_to_max(dm, g["d_mask_mask16"]) <= 2e-3
+
+
+from conftest import LOSS_CASES  # noqa: E402
+
+
+@pytest.mark.parametrize("case", LOSS_CASES)
+def test_sequence_loss_matches_reference(golden, case):
+    g = golden(case)
+    n = int(g["n"])
+    preds = [g[f"pred_{i}"] for i in range(n)]
+    loss, metrics, grads = U.sequence_loss(preds, g["gt"], g["valid"], float(g["gamma"]), float(g["max_flow"]))
+    assert abs(loss - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    for k, m in enumerate(("epe", "1px", "3px", "5px")):
+        assert abs(metrics[m] - float(g["metrics"][k])) <= 1e-5
+    for i in range(n):
+        assert U.rel_to_max(grads[i], g[f"d_pred_{i}"]) <= 1e-5
