@@ -231,7 +231,40 @@ def update_ops(cfg, device, n=50):
     t_upd_bwd = timed(lambda: torch.autograd.grad(hn, leaves, ghn, retain_graph=True))
     el = B * C * H * W
     up_bytes = B * H * W * (9 * f * f * s + 4 + f * f * 4)
-    return dict(gru_update_us=round(t_upd, 2), gru_update_gbps=round(6 * el * s / (t_upd * 1e-6) / 1e9, 1),
+    loss = {}
+    if cfg["train"]:
+        # sequence_loss over the iterations' full-resolution predictions (train_stereo.py:35-70), forward + backward
+        n = cfg["iters"]
+        gt = -torch.rand((B, 1, f * H, f * W), generator=g, device=device) * 100
+        valid = (torch.rand((B, f * H, f * W), generator=g, device=device) > 0.1).float()
+        preds = [(gt + torch.randn((B, 1, f * H, f * W), generator=g, device=device)).requires_grad_(True)
+                 for _ in range(n)]
+
+        def ours():
+            l, _ = R.sequence_loss_hip(preds, gt, valid)
+            l.backward()
+
+        def torch_loss():      # the reference's ops, masks included
+            vm = ((valid >= 0.5) & (torch.sum(gt ** 2, dim=1).sqrt() < 700)).unsqueeze(1)
+            tot = 0.0
+            for i in range(n):
+                tot = tot + 0.9 ** (15 / (n - 1) * (n - i - 1)) * (preds[i] - gt).abs()[vm.bool()].mean()
+            epe = torch.sum((preds[-1] - gt) ** 2, dim=1).sqrt().view(-1)[vm.view(-1)]
+            _ = (epe.mean().item(), (epe < 1).float().mean().item(), (epe < 3).float().mean().item(),
+                 (epe < 5).float().mean().item())
+            tot.backward()
+
+        def wall(fn, reps=10):
+            fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / reps * 1e3
+        loss = dict(sequence_loss_fwd_bwd_ms=round(wall(ours), 3), sequence_loss_torch_ms=round(wall(torch_loss), 3),
+                    sequence_loss_predictions=n)
+    return dict(**loss, gru_update_us=round(t_upd, 2), gru_update_gbps=round(6 * el * s / (t_upd * 1e-6) / 1e9, 1),
                 gru_gate_r_us=round(t_gate, 2), gru_gate_r_gbps=round(4 * el * s / (t_gate * 1e-6) / 1e9, 1),
                 gru_pointwise_torch_us=round(t_torch, 2),
                 upsample_us=round(t_up, 2), upsample_gbps=round(up_bytes / (t_up * 1e-6) / 1e9, 1),
@@ -383,7 +416,7 @@ def main():
 
     if not is_alt and not cfg["train"] and rank == 0:
         extra.update(fused_convc1(step, cfg, device))      # after the timed region: not part of `value`
-    if not cfg["train"] and rank == 0 and cfg["H"] * cfg["W"] * cfg["batch"] <= 300000:
+    if rank == 0 and cfg["H"] * cfg["W"] * cfg["batch"] <= 300000:
         extra.update(update_ops(cfg, device))              # side metrics, after the timed region
     if not cfg["train"] and world == 1:       # side metric; kept out of multi-rank runs (no capture beside RCCL)
         extra.update(hip_graph_step(step))
