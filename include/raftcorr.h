@@ -192,6 +192,22 @@ int rc_lookup_convc1_fwd(const void* vol, const rc_layout* lay, const float* coo
                          void* out, int radius, int coord_mode, int relu, void* stream);
 
 /*
+ * Adjoint of rc_lookup_convc1_fwd (autograd of core/update.py:78 on core/raft_stereo.py:110), so the fused
+ * layer also trains.  The caller recomputes corr = rc_lookup_fwd(coords) (float [B,K,H,W], K = L*(2r+1))
+ * right before the call -- the forward never stored it -- and passes the forward's output `act` (for the
+ * ReLU mask; `relu` as in the forward) and its gradient, both [B,64,H,W] of `dtype`, with the float weight
+ * [64,K] as nn.Conv2d stores it:
+ *     grad_corr   float [B,K,H,W]  = W^T (grad_act where act > 0)   -> the `grad_out` of rc_lookup_bwd(_dense)
+ *     grad_weight float [64,K], grad_bias float [64]                 (sums over all pixels)
+ * `work`: rc_convc1_bwd_work_bytes() of scratch (transposed weights + float block partials, which are added
+ * in double in a fixed order: no atomics, reproducible run to run).
+ */
+int64_t rc_convc1_bwd_work_bytes(void);
+int rc_convc1_bwd(const float* corr, const void* act, const void* grad_act, const float* weight,
+                  float* grad_corr, float* grad_weight, float* grad_bias, void* work, int64_t B,
+                  int in_channels, int64_t HW, int dtype, int relu, void* stream);
+
+/*
  * Drop-in for the reference's `corr_sampler` extension (sampler/sampler.cpp:48-51): one
  * level, the caller's row-major volume [B,H,W1,W2] of `dtype`, coords [B,coords_channels,H,W1]
  * float, corr / corr_grad [B,2r+1,H,W1] of `dtype`.  rc_sampler_bwd OVERWRITES volume_grad

@@ -15,6 +15,7 @@ the upstream tree, which is NOT shipped):
   pool_pyramid_bwd   adjoint of pool_pyramid
   corr_volume_bwd    adjoint of corr_volume
   alt_lookup         core/corr.py:64-107 (on-the-fly variant; equal to reg by linearity)
+  convc1_relu(_bwd)  core/update.py:71,78 (first layer of the motion encoder on a lookup result)
 
 Parity pin: the functions are checked in tests/test_oracle_golden.py against vectors
 captured from the reference's own Python (tests/golden/make_golden.py ran
@@ -238,6 +239,16 @@ def convc1_relu(corr, weight, bias, relu=True, round_to=None):
     if relu:
         out = np.maximum(out, 0.0)
     return out.astype(F32)
+
+
+def convc1_relu_bwd(corr, weight, bias, grad_act, relu=True):
+    """Adjoint of convc1_relu (autograd of core/update.py:71,78): (d corr, d weight [64,K], d bias [64])."""
+    corr = np.asarray(corr, dtype=np.float64)
+    w = np.asarray(weight, dtype=np.float64).reshape(np.asarray(weight).shape[0], -1)
+    pre = np.einsum("ok,bkhw->bohw", w, corr) + np.asarray(bias, dtype=np.float64)[None, :, None, None]
+    gm = np.asarray(grad_act, dtype=np.float64) * ((pre > 0) if relu else 1.0)
+    return (np.einsum("ok,bohw->bkhw", w, gm).astype(F32), np.einsum("bohw,bkhw->ok", gm, corr).astype(F32),
+            gm.sum(axis=(0, 2, 3)).astype(F32))
 
 
 # ----------------------------------------------------------------------------- helpers

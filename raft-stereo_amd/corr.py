@@ -168,6 +168,41 @@ class _LookupFn(torch.autograd.Function):
         return None, None, None     # autograd still runs the build's backward once all lookups have
 
 
+class _LookupConvc1Fn(torch.autograd.Function):
+    """relu(convc1(lookup(coords))) as one differentiable node.  Nothing but the 64-channel result is kept
+    for the backward: it recomputes the lookup, runs rc_convc1_bwd (tap, weight and bias gradients) and
+    queues the tap gradients for the build's fused adjoint like a plain lookup does."""
+
+    @staticmethod
+    def forward(ctx, token, coords, weight, bias, block, relu):
+        act = block._lookup_convc1(coords, weight, bias, relu)
+        ctx.block, ctx.coords, ctx.relu, ctx.has_token = block, coords, relu, token is not None
+        ctx.save_for_backward(act, weight, bias)
+        return act
+
+    @staticmethod
+    def backward(ctx, grad_act):
+        act, weight, bias = ctx.saved_tensors
+        block = ctx.block
+        K = block.num_levels * (2 * block.radius + 1)
+        dev = block.device
+        corr = block._lookup(ctx.coords)                      # recomputed: the forward never stored it
+        g = grad_act.to(act.dtype).contiguous()
+        w32 = weight.detach().reshape(_lib.RC_CONVC1_OUT, K).float().contiguous()
+        with torch.cuda.device(dev):
+            grad_corr = torch.empty_like(corr)
+            gw = torch.empty((_lib.RC_CONVC1_OUT, K), dtype=torch.float32, device=dev)
+            gb = torch.empty((_lib.RC_CONVC1_OUT,), dtype=torch.float32, device=dev)
+            work = torch.empty(int(lib.rc_convc1_bwd_work_bytes()), dtype=torch.uint8, device=dev)
+            check(lib.rc_convc1_bwd(corr.data_ptr(), act.data_ptr(), g.data_ptr(), w32.data_ptr(),
+                                    grad_corr.data_ptr(), gw.data_ptr(), gb.data_ptr(), work.data_ptr(), block.B, K,
+                                    block.H * block.W1, block.vol_dtype, int(ctx.relu), _stream(dev)),
+                  "rc_convc1_bwd")
+        if ctx.has_token:
+            block._pending.append((ctx.coords, grad_corr))    # taken by the build's backward
+        return None, None, gw.view(weight.shape).to(weight.dtype), gb.view(bias.shape).to(bias.dtype), None, None
+
+
 class CorrBlock1DHip:
     """`reg_hip`: materialised all-pairs 1-D correlation pyramid + per-iteration lookup.
 
@@ -259,9 +294,8 @@ class CorrBlock1DHip:
 
         weight: convc1.weight `[64, L*(2r+1), 1, 1]` (or `[64, L*(2r+1)]`), bias `[64]`.  Returns
         `[B, 64, H, W]` in the pyramid's dtype: fp16/bf16 under mixed precision (what autocast makes
-        of the convolution), fp32 otherwise.  Inference only (SURVEY.md section 8 f, rank 1)."""
-        if torch.is_grad_enabled() and (self._token is not None or weight.requires_grad or bias.requires_grad):
-            raise RuntimeError("lookup_convc1 is forward-only: call it under torch.no_grad()")
+        of the convolution), fp32 otherwise.  Differentiable w.r.t. the feature maps, weight and bias
+        (SURVEY.md section 8 f, rank 1): the backward recomputes the lookup instead of keeping it."""
         K = self.num_levels * (2 * self.radius + 1)
         if weight.numel() != _lib.RC_CONVC1_OUT * K or weight.shape[0] != _lib.RC_CONVC1_OUT \
                 or bias.numel() != _lib.RC_CONVC1_OUT:
@@ -272,6 +306,12 @@ class CorrBlock1DHip:
         if weight.device != self.device or bias.device != self.device:
             raise RuntimeError("convc1 parameters live on a different device than the feature maps")
         coords = _check_coords(coords, self.B, self.H, self.W1, self.device)
+        if torch.is_grad_enabled() and (self._token is not None or weight.requires_grad or bias.requires_grad):
+            return _LookupConvc1Fn.apply(self._token, coords, weight, bias, self, bool(relu))
+        return self._lookup_convc1(coords, weight, bias, relu)
+
+    def _lookup_convc1(self, coords, weight, bias, relu):
+        K = self.num_levels * (2 * self.radius + 1)
         key = (weight.data_ptr(), weight._version, bias.data_ptr(), bias._version)
         with torch.cuda.device(self.device):
             st = _stream(self.device)

@@ -9,7 +9,8 @@ It imports `core.update.BasicMotionEncoder` from the reference (its unused `opt_
 satisfied by an empty stand-in module), builds the encoder for the case's (levels, radius) with
 seeded random weights and applies its own `F.relu(self.convc1(corr))` (core/update.py:71,78) to the
 lookup results already stored by make_golden.py (outputs of the reference's CorrBlock1D).  Stored:
-convc1 weight, bias and the activations, in `convc1_<case>.npz`.  Only data is stored.
+convc1 weight, bias, the activations and, for a seeded random grad_act, the autograd gradients w.r.t. the
+lookup result, the weight and the bias, in `convc1_<case>.npz`.  Only data is stored.
 """
 import os
 import sys
@@ -42,6 +43,16 @@ if __name__ == "__main__":
             out = {"weight": enc.convc1.weight.numpy().copy(), "bias": enc.convc1.bias.numpy().copy()}
             for k in ("smooth", "random", "edge"):
                 out[f"act_{k}"] = F.relu(enc.convc1(torch.from_numpy(g[f"lookup_{k}"]))).numpy()
+        # autograd through the same two lines: gradients of a random grad_act w.r.t. corr, weight and bias
+        for j, k in enumerate(("smooth", "random", "edge")):
+            corr = torch.from_numpy(g[f"lookup_{k}"]).requires_grad_(True)
+            enc.zero_grad()
+            act = F.relu(enc.convc1(corr))
+            gact = torch.randn(act.shape, generator=torch.Generator().manual_seed(9000 + 10 * n + j))
+            act.backward(gact)
+            out[f"gact_{k}"], out[f"d_corr_{k}"] = gact.numpy(), corr.grad.numpy()
+            out[f"d_weight_{k}"], out[f"d_bias_{k}"] = enc.convc1.weight.grad.numpy().copy(), \
+                enc.convc1.bias.grad.numpy().copy()
         path = os.path.join(HERE, "convc1_" + case + ".npz")
         np.savez_compressed(path, **out)
         print(case, {k: v.shape for k, v in out.items()}, os.path.getsize(path) // 1024, "KiB")

@@ -507,15 +507,87 @@ def test_lookup_convc1_equals_unfused_at_full_size(R, dtype, shape, mode):
     assert rel(act, ref.cpu().numpy()) < tol
 
 
-def test_lookup_convc1_is_forward_only(R):
-    f = torch.randn(1, 32, 2, 32, device="cuda", requires_grad=True)
+def test_lookup_convc1_rejects_bad_weights(R):
+    f = torch.randn(1, 32, 2, 32, device="cuda")
     blk = R.CorrBlock1DHip(f, f)
     c = torch.zeros(1, 2, 2, 32, device="cuda")
-    with pytest.raises(RuntimeError):
-        blk.lookup_convc1(c, torch.zeros(64, 36, device="cuda"), torch.zeros(64, device="cuda"))
-    with torch.no_grad():
-        with pytest.raises(ValueError):
-            blk.lookup_convc1(c, torch.zeros(64, 35, device="cuda"), torch.zeros(64, device="cuda"))
+    with pytest.raises(ValueError):
+        blk.lookup_convc1(c, torch.zeros(64, 35, device="cuda"), torch.zeros(64, device="cuda"))
+
+
+@pytest.mark.parametrize("case", CONVC1_CASES)
+@pytest.mark.parametrize("kind", KINDS)
+def test_lookup_convc1_backward_fp32_matches_reference_autograd(R, golden, case, kind):
+    """Training through the fused layer: weight / bias gradients against the reference's BasicMotionEncoder
+    autograd, feature-map gradients against the two-step route (reg_hip lookup fed the reference's d corr),
+    which is itself pinned on the reference's CorrBlock1D autograd."""
+    g, c = golden(case), golden("convc1_" + case)
+    L, r = int(g["L"]), int(g["r"])
+    f1, f2 = dev(g["f1"]).requires_grad_(True), dev(g["f2"]).requires_grad_(True)
+    w, b = dev(c["weight"]).requires_grad_(True), dev(c["bias"]).requires_grad_(True)
+    coords = dev(g[f"coords_{kind}"])
+    blk = R.CorrBlock1DHip(f1, f2, num_levels=L, radius=r)
+    act = blk.lookup_convc1(coords, w, b)
+    assert rel(act, c[f"act_{kind}"]) < TOL32
+    act.backward(dev(c[f"gact_{kind}"]))
+    assert rel(w.grad, c[f"d_weight_{kind}"]) < TOL32
+    assert rel(b.grad, c[f"d_bias_{kind}"]) < TOL32
+    g1, g2 = dev(g["f1"]).requires_grad_(True), dev(g["f2"]).requires_grad_(True)
+    R.CorrBlock1DHip(g1, g2, num_levels=L, radius=r)(coords).backward(dev(c[f"d_corr_{kind}"]))
+    assert rel(f1.grad, g1.grad.cpu().numpy()) < TOL32
+    assert rel(f2.grad, g2.grad.cpu().numpy()) < TOL32
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_lookup_convc1_backward_equals_unfused_at_training_size(R, dtype):
+    """SceneFlow training shape, three lookups accumulated, frozen feature maps in one run (only the layer's
+    parameters train) and everything trainable in the other: against lookup -> torch conv -> relu."""
+    torch.manual_seed(8)
+    B, D, H, W = 8, 256, 80, 180
+    f1 = torch.randn(B, D, H, W, device="cuda").to(dtype)
+    f2 = torch.randn(B, D, H, W, device="cuda").to(dtype)
+    w = (torch.randn(64, 36, 1, 1, device="cuda") * 0.2)
+    b = torch.randn(64, device="cuda")
+    coords = [dev(O.synthetic_coords(B, H, W, seed=s)) for s in (1, 2, 3)]
+    gouts = [torch.randn(B, 64, H, W, device="cuda").to(dtype) for _ in coords]
+    tol = 2e-4 if dtype == torch.float32 else TOL16[dtype]
+
+    def run(fused, train_fmaps):
+        a1, a2 = f1.clone().requires_grad_(train_fmaps), f2.clone().requires_grad_(train_fmaps)
+        ww, bb = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        blk = R.CorrBlock1DHip(a1, a2)
+        outs = []
+        if fused:
+            outs = [blk.lookup_convc1(c, ww, bb) for c in coords]
+            torch.autograd.backward(outs, gouts)
+        elif dtype == torch.float32:
+            outs = [torch.relu(torch.nn.functional.conv2d(blk(c), ww, bb)) for c in coords]
+            torch.autograd.backward(outs, gouts)
+        else:
+            # 16-bit: the same arithmetic spelled out in fp32 on the fused run's own ReLU masks (torch's
+            # 16-bit convolution backward is too coarse to serve as a reference)
+            ww.grad, bb.grad = torch.zeros_like(ww), torch.zeros_like(bb)
+            corrs, dcorrs = [blk(c) for c in coords], []
+            for corr, act, go in zip(corrs, fused_outs, gouts):
+                gm = go.float() * (act > 0)
+                ww.grad += torch.einsum("bohw,bkhw->ok", gm, corr.detach()).view_as(ww)
+                bb.grad += gm.sum(dim=(0, 2, 3))
+                outs.append(act)
+                dcorrs.append(torch.einsum("ok,bohw->bkhw", ww.detach().view(64, 36), gm))
+            if train_fmaps:
+                torch.autograd.backward(corrs, dcorrs)
+        return [t.grad for t in (ww, bb, a1, a2)], outs
+
+    for train_fmaps in (False, True):
+        mine, fused_outs = run(True, train_fmaps)
+        ref, o2 = run(False, train_fmaps)
+        for x, y in zip(fused_outs, o2):
+            assert rel(x, y.detach().float().cpu().numpy()) < tol
+        for name, x, y in zip(("dW", "db", "df1", "df2"), mine, ref):
+            if y is None:
+                assert x is None
+                continue
+            assert rel(x, y.float().cpu().numpy()) < tol, (name, train_fmaps)
 
 
 # ------------------------------------------------------------------ coordinate glue in the lookup (SURVEY 8f rank 2)

@@ -101,6 +101,10 @@ def test_convc1_relu_matches_reference_motion_encoder(golden, case, kind):
     act = O.convc1_relu(corr, c["weight"], c["bias"])
     assert O.rel_to_max(act, c[f"act_{kind}"]) < 1e-5
     assert (c[f"act_{kind}"] == 0).any() and (c[f"act_{kind}"] > 0).any()   # the ReLU is exercised
+    dc, dw, db = O.convc1_relu_bwd(g[f"lookup_{kind}"], c["weight"], c["bias"], c[f"gact_{kind}"])
+    assert O.rel_to_max(dc, c[f"d_corr_{kind}"]) < 1e-5
+    assert O.rel_to_max(dw, c[f"d_weight_{kind}"].reshape(dw.shape)) < 1e-5
+    assert O.rel_to_max(db, c[f"d_bias_{kind}"]) < 1e-5
 
 
 def test_oracle_replays_the_reference_model_run(golden):
