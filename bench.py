@@ -262,7 +262,27 @@ def update_ops(cfg, device, n=50):
                 fn()
             torch.cuda.synchronize()
             return (time.perf_counter() - t0) / reps * 1e3
-        loss = dict(sequence_loss_fwd_bwd_ms=round(wall(ours), 3), sequence_loss_torch_ms=round(wall(torch_loss), 3),
+        # SURVEY 8(f) rank 1 in training: all iterations' lookup -> convc1 -> relu, forward + backward, fused
+        # (lookup recomputed in the backward, 64-channel activations kept) against lookup + torch's convolution
+        wgt = (torch.randn((64, LEVELS * (2 * RADIUS + 1), 1, 1), generator=g, device=device) * 0.2).requires_grad_(True)
+        bias = torch.randn((64,), generator=g, device=device).requires_grad_(True)
+        f1 = torch.randn((B, D, H, W), generator=g, device=device).to(dt).requires_grad_(True)
+        f2 = torch.randn((B, D, H, W), generator=g, device=device).to(dt).requires_grad_(True)
+        from oracle.corr_oracle import synthetic_coords
+        crd = torch.from_numpy(synthetic_coords(B, H, W, seed=5)).to(device)
+        gact = torch.randn((B, 64, H, W), generator=g, device=device).to(dt)
+
+        def c1_step(fused):
+            blk = R.CorrBlock1DHip(f1, f2, num_levels=LEVELS, radius=RADIUS)
+            if fused:
+                outs = [blk.lookup_convc1(crd, wgt, bias) for _ in range(n)]
+            else:
+                outs = [torch.relu(torch.nn.functional.conv2d(blk(crd).to(dt), wgt.to(dt), bias.to(dt)))
+                        for _ in range(n)]
+            torch.autograd.backward(outs, [gact] * n)
+        loss = dict(train_fused_convc1_ms=round(wall(lambda: c1_step(True)), 3),
+                    train_unfused_convc1_ms=round(wall(lambda: c1_step(False)), 3),
+                    sequence_loss_fwd_bwd_ms=round(wall(ours), 3), sequence_loss_torch_ms=round(wall(torch_loss), 3),
                     sequence_loss_predictions=n)
     return dict(**loss, gru_update_us=round(t_upd, 2), gru_update_gbps=round(6 * el * s / (t_upd * 1e-6) / 1e9, 1),
                 gru_gate_r_us=round(t_gate, 2), gru_gate_r_gbps=round(4 * el * s / (t_gate * 1e-6) / 1e9, 1),

@@ -9,8 +9,10 @@
 // convc1_bwd_taps_kernel: one pixel per lane, its 64 masked gradients in registers; the weights, transposed
 // to [k][o] in the workspace, arrive through scalar loads (the index is wave-uniform), so the 64 K
 // multiply-adds per pixel are plain v_fmac with a scalar operand.
-// convc1_bwd_weight_kernel: blocks stride over chunks of 64 pixels staged in LDS; thread (o, k mod 4) keeps
-// its dW entries in registers; float block partials are added in double in a fixed order by
+// convc1_bwd_weight_mfma_kernel: the weight and bias sums on the matrix cores (see there);
+// convc1_bwd_weight_kernel is the plain-VALU route for images whose planes are not whole 16-byte segments
+// (blocks stride over chunks of 64 pixels staged in LDS; thread (o, k mod 4) keeps its dW entries in
+// registers).  Either way float block partials are added in double in a fixed order by
 // convc1_bwd_reduce_kernel (no atomics, reproducible run to run).
 #include "rc_common.h"
 
@@ -104,15 +106,158 @@ __global__ __launch_bounds__(256) void convc1_bwd_weight_kernel(const float* __r
   if (kq == 0) mine[CB_OUT * K + o] = accb;
 }
 
-__global__ void convc1_bwd_reduce_kernel(const float* __restrict__ part, int nblk, int K, float* __restrict__ gw,
-                                         float* __restrict__ gb) {
+// ---- the same sums on the matrix cores (whole 16-byte pixel segments: HW % 8 == 0 for 16-bit, % 4 for f32).
+// dW[o][k] = sum_px gm[o][px] corr[k][px] is a [64 x P] x [P x K] product with the pixels as the contraction
+// index: an MFMA lane wants 8 (16-bit) or 4 (f32) consecutive pixels of ONE channel plane, which is one
+// 16-byte global load -- no LDS staging.  A wave owns groups of 32 (16) pixels and keeps the 4 x NT output
+// tiles in registers; column K of the last tile is fed ones, so it collects db.  The 4 waves of a block add
+// their tiles through LDS one after the other and the block writes one partial.
+typedef short cb_s8v __attribute__((ext_vector_type(8)));
+typedef _Float16 cb_h8v __attribute__((ext_vector_type(8)));
+typedef __bf16 cb_b8v __attribute__((ext_vector_type(8)));
+typedef float cb_f4v __attribute__((ext_vector_type(4)));
+typedef uint32_t cb_u4v __attribute__((ext_vector_type(4)));
+
+template <typename T> __device__ __forceinline__ cb_f4v cb_mfma16(cb_s8v a, cb_s8v b, cb_f4v c);
+template <> __device__ __forceinline__ cb_f4v cb_mfma16<rc_half>(cb_s8v a, cb_s8v b, cb_f4v c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(cb_h8v, a), __builtin_bit_cast(cb_h8v, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ cb_f4v cb_mfma16<rc_bf16>(cb_s8v a, cb_s8v b, cb_f4v c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cb_b8v, a), __builtin_bit_cast(cb_b8v, b), c, 0, 0, 0);
+}
+
+// keep the 16-bit halves of g whose counterpart in a is a positive number (sign-magnitude: 0x0001..0x7fff)
+__device__ __forceinline__ uint32_t cb_mask_pos16(uint32_t g, uint32_t a) {
+  const uint32_t lo = a & 0xffffu, hi = a >> 16;
+  const uint32_t mlo = (lo - 1u) < 0x7fffu ? 0xffffu : 0u;
+  const uint32_t mhi = (hi - 1u) < 0x7fffu ? 0xffff0000u : 0u;
+  return g & (mlo | mhi);
+}
+
+template <typename T> __device__ __forceinline__ uint32_t cb_pack2(float lo, float hi) {
+  typedef T v2 __attribute__((ext_vector_type(2)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const f2 f = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, v2));
+}
+
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void convc1_bwd_weight_mfma_kernel(const float* __restrict__ corr,
+                                                                     const T* __restrict__ act,
+                                                                     const T* __restrict__ gact,
+                                                                     float* __restrict__ part, int K, int64_t HW,
+                                                                     int64_t groups_per_image, int64_t n_groups,
+                                                                     int relu) {
+  constexpr bool IS16 = sizeof(T) == 2;
+  constexpr int SEG = IS16 ? 8 : 4;    // pixels per lane segment (16 bytes of T)
+  constexpr int GP = 4 * SEG;          // pixels per group
+  constexpr int LD = NT * 16;          // padded row of the block partial
+  __shared__ float red[CB_OUT * LD];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, i = lane & 15;
+  cb_f4v acc[4][NT];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (cb_f4v)(0.f);
+
+  for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < n_groups; grp += (int64_t)gridDim.x * 4) {
+    const int64_t b = grp / groups_per_image;
+    const int64_t p = (grp - b * groups_per_image) * GP + g * SEG;  // this lane's pixel segment
+    const bool in = p < HW;
+    const int64_t pc = in ? p : 0;
+    // A fragments: masked gradients of channel 16 mt + i
+    cb_u4v ga[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int64_t e = (b * CB_OUT + 16 * mt + i) * HW + pc;
+      cb_u4v gv = *reinterpret_cast<const cb_u4v*>(gact + e);
+      if (relu) {
+        const cb_u4v av = *reinterpret_cast<const cb_u4v*>(act + e);
+        if constexpr (IS16) {
+#pragma unroll
+          for (int d = 0; d < 4; ++d) gv[d] = cb_mask_pos16(gv[d], av[d]);
+        } else {
+#pragma unroll
+          for (int d = 0; d < 4; ++d) gv[d] = __uint_as_float(av[d]) > 0.f ? gv[d] : 0u;
+        }
+      }
+      ga[mt] = in ? gv : (cb_u4v)(0u);
+    }
+    // B fragments: corr of channel 16 nt + i (ones in column K: the bias gradient), zero beyond
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int k = 16 * nt + i;
+      const bool real = in && k < K;
+      const float* src = corr + (b * K + (k < K ? k : 0)) * HW + pc;
+      const float fill = (in && k == K) ? 1.f : 0.f;
+      if constexpr (IS16) {
+        const cb_f4v c0 = *reinterpret_cast<const cb_f4v*>(src), c1 = *reinterpret_cast<const cb_f4v*>(src + 4);
+        cb_u4v bv;
+        bv[0] = cb_pack2<T>(real ? c0[0] : fill, real ? c0[1] : fill);
+        bv[1] = cb_pack2<T>(real ? c0[2] : fill, real ? c0[3] : fill);
+        bv[2] = cb_pack2<T>(real ? c1[0] : fill, real ? c1[1] : fill);
+        bv[3] = cb_pack2<T>(real ? c1[2] : fill, real ? c1[3] : fill);
+        const cb_s8v bf = __builtin_bit_cast(cb_s8v, bv);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = cb_mfma16<T>(__builtin_bit_cast(cb_s8v, ga[mt]), bf, acc[mt][nt]);
+      } else {
+        const cb_f4v c0 = *reinterpret_cast<const cb_f4v*>(src);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {  // contraction slot g of step q = pixel 4 g + q, for A and B alike
+          const float bq = real ? c0[q] : fill;
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(ga[mt][q]), bq, acc[mt][nt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // lane (g, i) holds rows o = 16 mt + 4 g + r of column k = 16 nt + i; the waves add up in turn
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float* cell = red + (16 * mt + 4 * g + r) * LD + 16 * nt + i;
+            *cell = (w == 0 ? 0.f : *cell) + acc[mt][nt][r];
+          }
+    }
+    __syncthreads();
+  }
+  float* mine = part + (int64_t)blockIdx.x * (CB_OUT * K + CB_OUT);
+  for (int e = threadIdx.x; e < CB_OUT * (K + 1); e += 256) {
+    const int o = e / (K + 1), k = e - o * (K + 1);
+    const float v = red[o * LD + k];
+    if (k < K) mine[o * K + k] = v;
+    else mine[CB_OUT * K + o] = v;
+  }
+}
+
+// dW, db = sum of the block partials, in double, in a fixed order: 64 entries x 16 slices per block
+__global__ __launch_bounds__(1024) void convc1_bwd_reduce_kernel(const float* __restrict__ part, int nblk, int K,
+                                                                 float* __restrict__ gw, float* __restrict__ gb) {
+  __shared__ double sl[16][64];
   const int n = CB_OUT * K + CB_OUT;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)part[(int64_t)b * n + i];
-  if (i < CB_OUT * K) gw[i] = (float)s;
-  else gb[i - CB_OUT * K] = (float)s;
+  const int e = threadIdx.x & 63, s = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + e;
+  double sum = 0.0;
+  if (i < n) {
+#pragma unroll 4
+    for (int b = s; b < nblk; b += 16) sum += (double)part[(int64_t)b * n + i];
+  }
+  sl[s][e] = sum;
+  __syncthreads();
+  if (s == 0 && i < n) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += sl[q][e];
+    if (i < CB_OUT * K) gw[i] = (float)t;
+    else gb[i - CB_OUT * K] = (float)t;
+  }
 }
 
 template <typename T>
@@ -127,14 +272,36 @@ int launch_convc1_bwd(const float* corr, const void* act, const void* gact, cons
                      (const T*)act, (const T*)gact, wt, gcorr, K, HW, relu);
   rc = rc_check_launch("rc_convc1_bwd(taps)");
   if (rc) return rc;
-  const int64_t cpi = (HW + CB_PIX - 1) / CB_PIX, n_chunks = B * cpi;
-  const int nblk = (int)(n_chunks < CB_BLOCKS ? n_chunks : CB_BLOCKS);
-  hipLaunchKernelGGL((convc1_bwd_weight_kernel<T>), dim3(nblk), dim3(256), 0, st, corr, (const T*)act, (const T*)gact,
-                     part, K, HW, cpi, n_chunks, relu);
+  constexpr int SEG = 16 / (int)sizeof(T), GP = 4 * SEG;
+  const bool whole = HW % SEG == 0 && (uintptr_t)corr % 16 == 0 && (uintptr_t)act % 16 == 0 && (uintptr_t)gact % 16 == 0;
+  int nblk;
+  if (whole) {
+    const int64_t gpi = (HW + GP - 1) / GP, n_groups = B * gpi;
+    nblk = (int)((n_groups + 7) / 8 < CB_BLOCKS ? (n_groups + 7) / 8 : CB_BLOCKS);
+    const int NT = K / 16 + 1;
+#define RC_CB_LAUNCH(N)                                                                                          \
+  case N:                                                                                                        \
+    hipLaunchKernelGGL((convc1_bwd_weight_mfma_kernel<T, N>), dim3(nblk), dim3(256), 0, st, corr, (const T*)act, \
+                       (const T*)gact, part, K, HW, gpi, n_groups, relu);                                        \
+    break;
+    switch (NT) {
+      RC_CB_LAUNCH(1)
+      RC_CB_LAUNCH(2)
+      RC_CB_LAUNCH(3)
+      RC_CB_LAUNCH(4)
+      RC_CB_LAUNCH(5)
+    }
+#undef RC_CB_LAUNCH
+  } else {
+    const int64_t cpi = (HW + CB_PIX - 1) / CB_PIX, n_chunks = B * cpi;
+    nblk = (int)(n_chunks < CB_BLOCKS ? n_chunks : CB_BLOCKS);
+    hipLaunchKernelGGL((convc1_bwd_weight_kernel<T>), dim3(nblk), dim3(256), 0, st, corr, (const T*)act,
+                       (const T*)gact, part, K, HW, cpi, n_chunks, relu);
+  }
   rc = rc_check_launch("rc_convc1_bwd(weight)");
   if (rc) return rc;
   const int n = CB_OUT * K + CB_OUT;
-  hipLaunchKernelGGL(convc1_bwd_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, part, nblk, K, gw, gb);
+  hipLaunchKernelGGL(convc1_bwd_reduce_kernel, dim3((n + 63) / 64), dim3(1024), 0, st, part, nblk, K, gw, gb);
   return rc_check_launch("rc_convc1_bwd(reduce)");
 }
 
