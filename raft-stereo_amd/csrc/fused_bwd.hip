@@ -6,9 +6,10 @@
 // The forward never stored the L*(2r+1)-channel tensor; the caller recomputes it with rc_lookup_fwd right
 // before this call (one lookup kernel; no 36-channel tensor is kept alive across the GRU iterations).
 //
-// convc1_bwd_taps_kernel: one pixel per lane, its 64 masked gradients in registers; the weights, transposed
-// to [k][o] in the workspace, arrive through scalar loads (the index is wave-uniform), so the 64 K
-// multiply-adds per pixel are plain v_fmac with a scalar operand.
+// convc1_bwd_taps_mfma_kernel: the tap gradients on the matrix cores for 16-bit tensors (see there).
+// convc1_bwd_taps_kernel (f32, or planes that are not whole 16-byte segments): one pixel per lane, its 64 masked
+// gradients in registers; the weights, transposed to [k][o] in the workspace, arrive through scalar loads
+// (the index is wave-uniform), so the 64 K multiply-adds per pixel are plain v_fmac with a scalar operand.
 // convc1_bwd_weight_mfma_kernel: the weight and bias sums on the matrix cores (see there);
 // convc1_bwd_weight_kernel is the plain-VALU route for images whose planes are not whole 16-byte segments
 // (blocks stride over chunks of 64 pixels staged in LDS; thread (o, k mod 4) keeps its dW entries in
@@ -237,6 +238,86 @@ __global__ __launch_bounds__(256) void convc1_bwd_weight_mfma_kernel(const float
   }
 }
 
+// ---- tap gradients on the matrix cores (16-bit types, whole 16-byte segments):
+// grad_corr[k][px] = sum_o W[o][k] gm[o][px] is [K x 64] x [64 x P].  A block stages the masked gradients of 64
+// pixels in LDS as [o][px] (16-byte loads along the planes), each wave takes 16 of the pixels and reads its B
+// fragments (8 consecutive o of one pixel) back with 16-bit LDS reads; the A fragments are the weights, packed
+// once per call by convc1_pack_bwd_kernel.  Results leave as 64-byte runs of each tap plane.
+constexpr int CB_GP = 66;  // LDS row pitch in 16-bit elements: 33 dwords, so the 4 lane rows of a read hit 4 bank groups
+
+template <typename T>
+__global__ void convc1_pack_bwd_kernel(const float* __restrict__ w, T* __restrict__ wp, int K) {
+  // wp[((nt*2 + s)*64 + lane)*8 + j] = W[o = 32 s + 8 g + j][k = 16 nt + i],  lane = 16 g + i
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nt_total = K / 16 + 1;
+  if (e >= nt_total * 2 * 64 * 8) return;
+  const int j = e & 7, lane = (e >> 3) & 63, s = (e >> 9) & 1, nt = e >> 10;
+  const int k = 16 * nt + (lane & 15), o = 32 * s + 8 * (lane >> 4) + j;
+  wp[e] = rc_from_float<T>(k < K ? w[o * K + k] : 0.f);
+}
+
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void convc1_bwd_taps_mfma_kernel(const T* __restrict__ act, const T* __restrict__ gact,
+                                                                   const T* __restrict__ wp, float* __restrict__ gcorr,
+                                                                   int K, int64_t HW, int relu) {
+  __shared__ uint16_t Gs[CB_OUT * CB_GP];
+  const int64_t b = blockIdx.y, p0 = (int64_t)blockIdx.x * 64;
+  {
+    const int seg = threadIdx.x & 7;
+    const int64_t p = p0 + 8 * seg;
+    const bool in = p < HW;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int o = (threadIdx.x >> 3) + 32 * h;
+      cb_u4v gv = (cb_u4v)(0u);
+      if (in) {
+        const int64_t e = (b * CB_OUT + o) * HW + p;
+        gv = *reinterpret_cast<const cb_u4v*>(gact + e);
+        if (relu) {
+          const cb_u4v av = *reinterpret_cast<const cb_u4v*>(act + e);
+#pragma unroll
+          for (int d = 0; d < 4; ++d) gv[d] = cb_mask_pos16(gv[d], av[d]);
+        }
+      }
+      uint32_t* dst = reinterpret_cast<uint32_t*>(Gs + o * CB_GP + 8 * seg);
+#pragma unroll
+      for (int d = 0; d < 4; ++d) dst[d] = gv[d];
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, i = lane & 15;
+  cb_f4v acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc[nt] = (cb_f4v)(0.f);
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    cb_u4v bv;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const uint32_t lo = Gs[(32 * s + 8 * g + 2 * d) * CB_GP + 16 * wave + i];
+      const uint32_t hi = Gs[(32 * s + 8 * g + 2 * d + 1) * CB_GP + 16 * wave + i];
+      bv[d] = lo | (hi << 16);
+    }
+    const cb_s8v bf = __builtin_bit_cast(cb_s8v, bv);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const cb_u4v av = *reinterpret_cast<const cb_u4v*>(wp + ((nt * 2 + s) * 64 + lane) * 8);
+      acc[nt] = cb_mfma16<T>(__builtin_bit_cast(cb_s8v, av), bf, acc[nt]);
+    }
+  }
+  const int64_t p = p0 + 16 * wave + i;
+  if (p < HW) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = 16 * nt + 4 * g + r;
+        if (k < K) gcorr[(b * K + k) * HW + p] = acc[nt][r];
+      }
+  }
+}
+
 // dW, db = sum of the block partials, in double, in a fixed order: 64 entries x 16 slices per block
 __global__ __launch_bounds__(1024) void convc1_bwd_reduce_kernel(const float* __restrict__ part, int nblk, int K,
                                                                  float* __restrict__ gw, float* __restrict__ gb) {
@@ -263,17 +344,42 @@ __global__ __launch_bounds__(1024) void convc1_bwd_reduce_kernel(const float* __
 template <typename T>
 int launch_convc1_bwd(const float* corr, const void* act, const void* gact, const float* weight, float* gcorr,
                       float* gw, float* gb, float* work, int64_t B, int K, int64_t HW, int relu, hipStream_t st) {
-  float* wt = work;
+  float* wt = work;                                  // [K][64] floats, or the MFMA-packed 16-bit weights
   float* part = work + CB_KMAX * CB_OUT;
-  hipLaunchKernelGGL(convc1_transpose_kernel, dim3((K * CB_OUT + 255) / 256), dim3(256), 0, st, weight, wt, K);
-  int rc = rc_check_launch("rc_convc1_bwd(transpose)");
-  if (rc) return rc;
-  hipLaunchKernelGGL((convc1_bwd_taps_kernel<T>), dim3((unsigned)((HW + 255) / 256), (unsigned)B), dim3(256), 0, st,
-                     (const T*)act, (const T*)gact, wt, gcorr, K, HW, relu);
-  rc = rc_check_launch("rc_convc1_bwd(taps)");
-  if (rc) return rc;
   constexpr int SEG = 16 / (int)sizeof(T), GP = 4 * SEG;
   const bool whole = HW % SEG == 0 && (uintptr_t)corr % 16 == 0 && (uintptr_t)act % 16 == 0 && (uintptr_t)gact % 16 == 0;
+  int rc;
+  if constexpr (sizeof(T) == 2) {
+    if (whole) {
+      const int NTt = K / 16 + 1;
+      hipLaunchKernelGGL((convc1_pack_bwd_kernel<T>), dim3((NTt * 1024 + 255) / 256), dim3(256), 0, st, weight, (T*)wt, K);
+      rc = rc_check_launch("rc_convc1_bwd(pack)");
+      if (rc) return rc;
+      const dim3 grid((unsigned)((HW + 63) / 64), (unsigned)B);
+#define RC_CB_TAPS(N)                                                                                              \
+  case N:                                                                                                          \
+    hipLaunchKernelGGL((convc1_bwd_taps_mfma_kernel<T, N>), grid, dim3(256), 0, st, (const T*)act, (const T*)gact, \
+                       (const T*)wt, gcorr, K, HW, relu);                                                          \
+    break;
+      switch (NTt) {
+        RC_CB_TAPS(1)
+        RC_CB_TAPS(2)
+        RC_CB_TAPS(3)
+        RC_CB_TAPS(4)
+        RC_CB_TAPS(5)
+      }
+#undef RC_CB_TAPS
+    }
+  }
+  if (sizeof(T) != 2 || !whole) {
+    hipLaunchKernelGGL(convc1_transpose_kernel, dim3((K * CB_OUT + 255) / 256), dim3(256), 0, st, weight, wt, K);
+    rc = rc_check_launch("rc_convc1_bwd(transpose)");
+    if (rc) return rc;
+    hipLaunchKernelGGL((convc1_bwd_taps_kernel<T>), dim3((unsigned)((HW + 255) / 256), (unsigned)B), dim3(256), 0, st,
+                       (const T*)act, (const T*)gact, wt, gcorr, K, HW, relu);
+  }
+  rc = rc_check_launch("rc_convc1_bwd(taps)");
+  if (rc) return rc;
   int nblk;
   if (whole) {
     const int64_t gpi = (HW + GP - 1) / GP, n_groups = B * gpi;
