@@ -214,6 +214,23 @@ def update_ops(cfg, device, n=50):
         u = torch.nn.functional.unfold(f * flow, [3, 3], padding=1).view(B, 2, 9, 1, 1, H, W)
         return torch.sum(m * u, dim=2).permute(0, 1, 4, 2, 5, 3).reshape(B, 2, f * H, f * W)[:, :1]
 
+    # the whole gru08 of the default model (hidden 128, inputs 128 + 128): ConvGRUHip against the reference's
+    # forward spelled with torch ops on the same parameters (convolutions are torch's in both)
+    gru = R.ConvGRUHip(C, 2 * C).to(device)
+    xm = torch.randn((B, C, H, W), generator=g, device=device)            # motion features are fp32 (update.py:85)
+    xu = torch.randn((B, C, H, W), generator=g, device=device).to(dt)
+
+    def torch_convgru():
+        x = torch.cat([xm, xu], dim=1)
+        hx = torch.cat([h, x], dim=1)
+        z = torch.sigmoid(gru.convz(hx) + cz)
+        r = torch.sigmoid(gru.convr(hx) + cr)
+        q = torch.tanh(gru.convq(torch.cat([r * h, x], dim=1)) + cq)
+        return (1 - z) * h + z * q
+
+    with torch.no_grad(), torch.autocast("cuda", dtype=dt, enabled=dt != torch.float32):
+        t_gru_mod = timed(lambda: gru(h, cz, cr, cq, xm, xu), )
+        t_gru_mod_torch = timed(torch_convgru)
     with torch.no_grad():
         t_upd = timed(lambda: R.gru_update(zc, cz, qc, cq, h))
         t_gate = timed(lambda: R.gru_gate_r(rc, cr, h))
@@ -287,6 +304,7 @@ def update_ops(cfg, device, n=50):
     return dict(**loss, gru_update_us=round(t_upd, 2), gru_update_gbps=round(6 * el * s / (t_upd * 1e-6) / 1e9, 1),
                 gru_gate_r_us=round(t_gate, 2), gru_gate_r_gbps=round(4 * el * s / (t_gate * 1e-6) / 1e9, 1),
                 gru_pointwise_torch_us=round(t_torch, 2),
+                convgru_module_us=round(t_gru_mod, 2), convgru_module_torch_us=round(t_gru_mod_torch, 2),
                 upsample_us=round(t_up, 2), upsample_gbps=round(up_bytes / (t_up * 1e-6) / 1e9, 1),
                 upsample_torch_us=round(t_up_torch, 2), upsample_bwd_us=round(t_up_bwd, 2),
                 gru_update_bwd_us=round(t_upd_bwd, 2))

@@ -251,9 +251,10 @@ int rc_alt_fwd(const void* f1t, const void* f2t, const rc_alt_layout* lay, int i
  *     rc_gru_gate_r:  rh = sigmoid(convr_out + cr) * h                                (update.py:28-29)
  *     rc_gru_update:  h_out = (1 - z) * h + z * q,  z = sigmoid(convz_out + cz),
  *                                                   q = tanh(convq_out + cq)          (update.py:27,29,31)
- * All tensors are [N, C, H, W] of `dtype` with per_batch = C*H*W elements per image.  convX_out, h, h_out
- * are contiguous; cz/cr/cq may be channel slices of a wider tensor (the `.split` views of
- * core/raft_stereo.py:88) and rh may be a channel slice of the buffer the next convolution reads
+ * All tensors are [N, C, H, W] of `dtype` with per_batch = C*H*W elements per image.  h and h_out are
+ * contiguous; in the forward calls convX_out may be channel slices of a wider tensor (convz and convr read the
+ * same input, so a caller may run them as one stacked convolution), cz/cr/cq likewise (the `.split` views of
+ * core/raft_stereo.py:88), and rh may be a channel slice of the buffer the next convolution reads
  * ([r*h, x], update.py:29): those take the distance between images in elements.  h_out may alias h.
  * 16-bit types round after every elementary operation, as the chain of torch ops under autocast does.
  * The _bwd twins are the adjoints (gates recomputed from the saved pre-activations):
@@ -261,12 +262,13 @@ int rc_alt_fwd(const void* f1t, const void* f2t, const rc_alt_layout* lay, int i
  *     rc_gru_gate_r_bwd: grad_r_pre (for convr_out and cr), grad_h (+)= grad_rh * r  (accumulate_grad_h != 0
  *                        adds to what grad_h holds: h is used by both kernels)
  */
-int rc_gru_gate_r(const void* convr_out, const void* cr, int64_t cr_batch_stride, const void* h,
-                  void* rh, int64_t rh_batch_stride, int64_t N, int64_t per_batch, int dtype,
-                  void* stream);
-int rc_gru_update(const void* convz_out, const void* cz, int64_t cz_batch_stride,
-                  const void* convq_out, const void* cq, int64_t cq_batch_stride, const void* h,
-                  void* h_out, int64_t N, int64_t per_batch, int dtype, void* stream);
+int rc_gru_gate_r(const void* convr_out, int64_t convr_batch_stride, const void* cr,
+                  int64_t cr_batch_stride, const void* h, void* rh, int64_t rh_batch_stride, int64_t N,
+                  int64_t per_batch, int dtype, void* stream);
+int rc_gru_update(const void* convz_out, int64_t convz_batch_stride, const void* cz,
+                  int64_t cz_batch_stride, const void* convq_out, int64_t convq_batch_stride,
+                  const void* cq, int64_t cq_batch_stride, const void* h, void* h_out, int64_t N,
+                  int64_t per_batch, int dtype, void* stream);
 int rc_gru_update_bwd(const void* convz_out, const void* cz, int64_t cz_batch_stride,
                       const void* convq_out, const void* cq, int64_t cq_batch_stride, const void* h,
                       const void* grad_h_out, void* grad_z_pre, void* grad_q_pre, void* grad_h,

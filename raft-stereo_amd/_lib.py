@@ -67,8 +67,8 @@ SIGNATURES = {
     "rc_alt_layout_init": (_I, [_L, _L, _L, _L, _L, _I, _ALP]),
     "rc_alt_prepare": (_I, [_P, _P, _P, _P, _ALP, _I, _P]),
     "rc_alt_fwd": (_I, [_P, _P, _ALP, _I, _P, _I, _P, _I, _I, _P]),
-    "rc_gru_gate_r": (_I, [_P, _P, _L, _P, _P, _L, _L, _L, _I, _P]),
-    "rc_gru_update": (_I, [_P, _P, _L, _P, _P, _L, _P, _P, _L, _L, _I, _P]),
+    "rc_gru_gate_r": (_I, [_P, _L, _P, _L, _P, _P, _L, _L, _L, _I, _P]),
+    "rc_gru_update": (_I, [_P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _L, _L, _I, _P]),
     "rc_gru_update_bwd": (_I, [_P, _P, _L, _P, _P, _L, _P, _P, _P, _P, _P, _L, _L, _I, _P]),
     "rc_gru_gate_r_bwd": (_I, [_P, _P, _L, _P, _P, _L, _P, _P, _I, _L, _L, _I, _P]),
     "rc_upsample_flow_fwd": (_I, [_P, _L, _P, _P, _L, _I, _L, _L, _I, _I, _P]),

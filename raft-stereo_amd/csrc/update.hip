@@ -51,14 +51,15 @@ __device__ __forceinline__ typename pw_vec<T, VEC>::type pw_load(const T* p) {
 
 // r*h of core/update.py:28-29:  r = sigmoid(convr(hx) + cr);  out = r * h
 template <typename T, int VEC>
-__global__ __launch_bounds__(PW_THREADS) void gru_gate_r_kernel(const T* __restrict__ convr, const T* __restrict__ cr,
-                                                                int64_t cr_bs, const T* __restrict__ h,
+__global__ __launch_bounds__(PW_THREADS) void gru_gate_r_kernel(const T* __restrict__ convr, int64_t convr_bs,
+                                                                const T* __restrict__ cr, int64_t cr_bs,
+                                                                const T* __restrict__ h,
                                                                 T* __restrict__ rh, int64_t rh_bs, int64_t per_batch,
                                                                 int64_t total) {
   const int64_t i = ((int64_t)blockIdx.x * PW_THREADS + threadIdx.x) * VEC;  // inside image b = blockIdx.y
   if (i >= per_batch) return;
   const int64_t b = blockIdx.y, e = b * per_batch + i;
-  const auto a = pw_load<T, VEC>(convr + e);
+  const auto a = pw_load<T, VEC>(convr + b * convr_bs + i);
   const auto c = pw_load<T, VEC>(cr + b * cr_bs + i);
   const auto hv = pw_load<T, VEC>(h + e);
   typename pw_vec<T, VEC>::type o;
@@ -73,17 +74,18 @@ __global__ __launch_bounds__(PW_THREADS) void gru_gate_r_kernel(const T* __restr
 
 // core/update.py:27,29,31:  z = sigmoid(convz(hx) + cz);  q = tanh(convq([r*h, x]) + cq);  h = (1-z)*h + z*q
 template <typename T, int VEC>
-__global__ __launch_bounds__(PW_THREADS) void gru_update_kernel(const T* __restrict__ convz, const T* __restrict__ cz,
-                                                                int64_t cz_bs, const T* __restrict__ convq,
+__global__ __launch_bounds__(PW_THREADS) void gru_update_kernel(const T* __restrict__ convz, int64_t convz_bs,
+                                                                const T* __restrict__ cz, int64_t cz_bs,
+                                                                const T* __restrict__ convq, int64_t convq_bs,
                                                                 const T* __restrict__ cq, int64_t cq_bs,
                                                                 const T* h, T* h_out, int64_t per_batch,
                                                                 int64_t total) {
   const int64_t i = ((int64_t)blockIdx.x * PW_THREADS + threadIdx.x) * VEC;  // inside image b = blockIdx.y
   if (i >= per_batch) return;
   const int64_t b = blockIdx.y, e = b * per_batch + i;
-  const auto az = pw_load<T, VEC>(convz + e);
+  const auto az = pw_load<T, VEC>(convz + b * convz_bs + i);
   const auto bz = pw_load<T, VEC>(cz + b * cz_bs + i);
-  const auto aq = pw_load<T, VEC>(convq + e);
+  const auto aq = pw_load<T, VEC>(convq + b * convq_bs + i);
   const auto bq = pw_load<T, VEC>(cq + b * cq_bs + i);
   const auto hv = pw_load<T, VEC>(h + e);
   typename pw_vec<T, VEC>::type o;
@@ -177,41 +179,42 @@ inline int pw_check(int64_t N, int64_t per_batch, int dtype) {
 }
 
 template <typename T>
-int launch_gate_r(const void* convr, const void* cr, int64_t cr_bs, const void* h, void* rh, int64_t rh_bs,
+int launch_gate_r(const void* convr, int64_t convr_bs, const void* cr, int64_t cr_bs, const void* h, void* rh,
+                  int64_t rh_bs,
                   int64_t N, int64_t per_batch, hipStream_t st) {
   constexpr int V = 16 / (int)sizeof(T);
   const int64_t total = N * per_batch;
-  const bool vec = per_batch % V == 0 && cr_bs % V == 0 && rh_bs % V == 0 && aligned16(convr) && aligned16(cr) &&
+  const bool vec = per_batch % V == 0 && convr_bs % V == 0 && cr_bs % V == 0 && rh_bs % V == 0 && aligned16(convr) && aligned16(cr) &&
                    aligned16(h) && aligned16(rh);
   dim3 blocks;
   int rc = pw_blocks(N, per_batch, vec ? V : 1, &blocks);
   if (rc) return rc;
   if (vec)
-    hipLaunchKernelGGL((gru_gate_r_kernel<T, V>), blocks, dim3(PW_THREADS), 0, st, (const T*)convr,
+    hipLaunchKernelGGL((gru_gate_r_kernel<T, V>), blocks, dim3(PW_THREADS), 0, st, (const T*)convr, convr_bs,
                        (const T*)cr, cr_bs, (const T*)h, (T*)rh, rh_bs, per_batch, total);
   else
-    hipLaunchKernelGGL((gru_gate_r_kernel<T, 1>), blocks, dim3(PW_THREADS), 0, st, (const T*)convr,
+    hipLaunchKernelGGL((gru_gate_r_kernel<T, 1>), blocks, dim3(PW_THREADS), 0, st, (const T*)convr, convr_bs,
                        (const T*)cr, cr_bs, (const T*)h, (T*)rh, rh_bs, per_batch, total);
   return rc_check_launch("rc_gru_gate_r");
 }
 
 template <typename T>
-int launch_update(const void* convz, const void* cz, int64_t cz_bs, const void* convq, const void* cq,
-                  int64_t cq_bs, const void* h, void* h_out, int64_t N, int64_t per_batch, hipStream_t st) {
+int launch_update(const void* convz, int64_t convz_bs, const void* cz, int64_t cz_bs, const void* convq,
+                  int64_t convq_bs, const void* cq, int64_t cq_bs, const void* h, void* h_out, int64_t N, int64_t per_batch, hipStream_t st) {
   constexpr int V = 16 / (int)sizeof(T);
   const int64_t total = N * per_batch;
-  const bool vec = per_batch % V == 0 && cz_bs % V == 0 && cq_bs % V == 0 && aligned16(convz) && aligned16(cz) &&
+  const bool vec = per_batch % V == 0 && convz_bs % V == 0 && convq_bs % V == 0 && cz_bs % V == 0 && cq_bs % V == 0 && aligned16(convz) && aligned16(cz) &&
                    aligned16(convq) && aligned16(cq) && aligned16(h) && aligned16(h_out);
   dim3 blocks;
   int rc = pw_blocks(N, per_batch, vec ? V : 1, &blocks);
   if (rc) return rc;
   if (vec)
-    hipLaunchKernelGGL((gru_update_kernel<T, V>), blocks, dim3(PW_THREADS), 0, st, (const T*)convz,
-                       (const T*)cz, cz_bs, (const T*)convq, (const T*)cq, cq_bs, (const T*)h, (T*)h_out, per_batch,
+    hipLaunchKernelGGL((gru_update_kernel<T, V>), blocks, dim3(PW_THREADS), 0, st, (const T*)convz, convz_bs,
+                       (const T*)cz, cz_bs, (const T*)convq, convq_bs, (const T*)cq, cq_bs, (const T*)h, (T*)h_out, per_batch,
                        total);
   else
-    hipLaunchKernelGGL((gru_update_kernel<T, 1>), blocks, dim3(PW_THREADS), 0, st, (const T*)convz,
-                       (const T*)cz, cz_bs, (const T*)convq, (const T*)cq, cq_bs, (const T*)h, (T*)h_out, per_batch,
+    hipLaunchKernelGGL((gru_update_kernel<T, 1>), blocks, dim3(PW_THREADS), 0, st, (const T*)convz, convz_bs,
+                       (const T*)cz, cz_bs, (const T*)convq, convq_bs, (const T*)cq, cq_bs, (const T*)h, (T*)h_out, per_batch,
                        total);
   return rc_check_launch("rc_gru_update");
 }
@@ -589,28 +592,31 @@ int launch_upsample_f(const float* flow, int64_t flow_bs, const void* mask, floa
   }                                                           \
   return RC_EUNSUPPORTED;
 
-extern "C" int rc_gru_gate_r(const void* convr_out, const void* cr, int64_t cr_batch_stride, const void* h,
-                             void* rh, int64_t rh_batch_stride, int64_t N, int64_t per_batch, int dtype,
+extern "C" int rc_gru_gate_r(const void* convr_out, int64_t convr_batch_stride, const void* cr,
+                             int64_t cr_batch_stride, const void* h, void* rh, int64_t rh_batch_stride, int64_t N, int64_t per_batch, int dtype,
                              void* stream) {
   RC_REQUIRE(convr_out && cr && h && rh, RC_EINVAL, "null pointer argument");
   int rc = pw_check(N, per_batch, dtype);
   if (rc) return rc;
-  RC_REQUIRE(cr_batch_stride >= per_batch && rh_batch_stride >= per_batch, RC_EINVAL,
-             "a batch stride is shorter than one image (%lld)", (long long)per_batch);
+  RC_REQUIRE(convr_batch_stride >= per_batch && cr_batch_stride >= per_batch && rh_batch_stride >= per_batch,
+             RC_EINVAL, "a batch stride is shorter than one image (%lld)", (long long)per_batch);
   hipStream_t st = (hipStream_t)stream;
-  RC_PW_DISPATCH(dtype, (launch_gate_r<T>(convr_out, cr, cr_batch_stride, h, rh, rh_batch_stride, N, per_batch, st)))
+  RC_PW_DISPATCH(dtype, (launch_gate_r<T>(convr_out, convr_batch_stride, cr, cr_batch_stride, h, rh, rh_batch_stride, N, per_batch, st)))
 }
 
-extern "C" int rc_gru_update(const void* convz_out, const void* cz, int64_t cz_batch_stride, const void* convq_out,
+extern "C" int rc_gru_update(const void* convz_out, int64_t convz_batch_stride, const void* cz,
+                             int64_t cz_batch_stride, const void* convq_out, int64_t convq_batch_stride,
                              const void* cq, int64_t cq_batch_stride, const void* h, void* h_out, int64_t N,
                              int64_t per_batch, int dtype, void* stream) {
   RC_REQUIRE(convz_out && cz && convq_out && cq && h && h_out, RC_EINVAL, "null pointer argument");
   int rc = pw_check(N, per_batch, dtype);
   if (rc) return rc;
-  RC_REQUIRE(cz_batch_stride >= per_batch && cq_batch_stride >= per_batch, RC_EINVAL,
+  RC_REQUIRE(cz_batch_stride >= per_batch && cq_batch_stride >= per_batch && convz_batch_stride >= per_batch &&
+                 convq_batch_stride >= per_batch, RC_EINVAL,
              "a batch stride is shorter than one image (%lld)", (long long)per_batch);
   hipStream_t st = (hipStream_t)stream;
-  RC_PW_DISPATCH(dtype, (launch_update<T>(convz_out, cz, cz_batch_stride, convq_out, cq, cq_batch_stride, h, h_out,
+  RC_PW_DISPATCH(dtype, (launch_update<T>(convz_out, convz_batch_stride, cz, cz_batch_stride, convq_out,
+                                          convq_batch_stride, cq, cq_batch_stride, h, h_out,
                                           N, per_batch, st)))
 }
 

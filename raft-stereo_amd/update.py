@@ -59,8 +59,9 @@ class _GateRFn(torch.autograd.Function):
 
 def _gate_r_raw(convr_out, cr_t, cr_bs, h, dst):
     N, per = h.shape[0], h[0].numel()
+    convr_out, conv_bs = _batch_view(convr_out, h, "convr_out")
     with _on_device(h.device):
-        check(lib.rc_gru_gate_r(convr_out.data_ptr(), cr_t.data_ptr(), cr_bs, h.data_ptr(), dst.data_ptr(),
+        check(lib.rc_gru_gate_r(convr_out.data_ptr(), conv_bs, cr_t.data_ptr(), cr_bs, h.data_ptr(), dst.data_ptr(),
                                 dst.stride(0) if N > 1 else per, N, per, _DT[h.dtype], _stream(h.device)),
               "rc_gru_gate_r")
 
@@ -75,7 +76,7 @@ class _UpdateFn(torch.autograd.Function):
         N, per = h.shape[0], h[0].numel()
         out = torch.empty_like(h)
         with _on_device(h.device):
-            check(lib.rc_gru_update(convz_out.data_ptr(), cz_t.data_ptr(), cz_bs, convq_out.data_ptr(),
+            check(lib.rc_gru_update(convz_out.data_ptr(), per, cz_t.data_ptr(), cz_bs, convq_out.data_ptr(), per,
                                     cq_t.data_ptr(), cq_bs, h.data_ptr(), out.data_ptr(), N, per, _DT[h.dtype],
                                     _stream(h.device)), "rc_gru_update")
         ctx.save_for_backward(convz_out, cz_t, convq_out, cq_t, h)
@@ -109,11 +110,11 @@ def gru_gate_r(convr_out, cr, h, out=None):
     [N,C,H,W] channel slice of a wider buffer: the first hidden_dim channels of `torch.cat([r*h, x], dim=1)`."""
     for t, w in ((convr_out, "convr_out"), (cr, "cr"), (h, "h")):
         _check_gru_operand(t, w)
-    convr_out, h = convr_out.contiguous(), h.contiguous()
+    h = h.contiguous()
     if convr_out.shape != h.shape or convr_out.dtype != h.dtype:
         raise ValueError("convr_out must match h")
     if out is None:
-        return _GateRFn.apply(convr_out, cr, h)
+        return _GateRFn.apply(convr_out.contiguous(), cr, h)
     if torch.is_grad_enabled() and (convr_out.requires_grad or cr.requires_grad or h.requires_grad):
         raise RuntimeError("gru_gate_r(out=...) writes in place and is forward-only")
     if out.shape != h.shape or out.dtype != h.dtype or out.stride()[1:] != h.stride()[1:] \
@@ -128,11 +129,24 @@ def gru_update(convz_out, cz, convq_out, cq, h):
     """`(1-z)*h + z*q` with `z = sigmoid(convz_out + cz)`, `q = tanh(convq_out + cq)` (core/update.py:27-31)."""
     for t, w in ((convz_out, "convz_out"), (cz, "cz"), (convq_out, "convq_out"), (cq, "cq"), (h, "h")):
         _check_gru_operand(t, w)
-    convz_out, convq_out, h = convz_out.contiguous(), convq_out.contiguous(), h.contiguous()
+    h = h.contiguous()
     if convz_out.shape != h.shape or convq_out.shape != h.shape or convz_out.dtype != h.dtype \
             or convq_out.dtype != h.dtype:
         raise ValueError("convz_out and convq_out must match h")
-    return _UpdateFn.apply(convz_out, cz, convq_out, cq, h)
+    if torch.is_grad_enabled() and any(t.requires_grad for t in (convz_out, cz, convq_out, cq, h)):
+        return _UpdateFn.apply(convz_out.contiguous(), cz, convq_out.contiguous(), cq, h)
+    # inference: the convolution outputs may be channel slices of a stacked convolution's result
+    zc, z_bs = _batch_view(convz_out.detach(), h, "convz_out")
+    qc, q_bs = _batch_view(convq_out.detach(), h, "convq_out")
+    cz_t, cz_bs = _batch_view(cz.detach(), h, "cz")
+    cq_t, cq_bs = _batch_view(cq.detach(), h, "cq")
+    N, per = h.shape[0], h[0].numel()
+    out = torch.empty_like(h)
+    with _on_device(h.device):
+        check(lib.rc_gru_update(zc.data_ptr(), z_bs, cz_t.data_ptr(), cz_bs, qc.data_ptr(), q_bs, cq_t.data_ptr(),
+                                cq_bs, h.data_ptr(), out.data_ptr(), N, per, _DT[h.dtype], _stream(h.device)),
+              "rc_gru_update")
+    return out
 
 
 class ConvGRUHip(nn.Module):
@@ -148,24 +162,39 @@ class ConvGRUHip(nn.Module):
         self.convr = nn.Conv2d(hidden_dim + input_dim, hidden_dim, kernel_size, padding=kernel_size // 2)
         self.convq = nn.Conv2d(hidden_dim + input_dim, hidden_dim, kernel_size, padding=kernel_size // 2)
 
+    def _stacked(self, dt):
+        """convz and convr as one convolution: stacked weight and bias, cached while the parameters stand still."""
+        key = (dt, self.convz.weight._version, self.convr.weight._version, self.convz.bias._version,
+               self.convr.bias._version, self.convz.weight.data_ptr(), self.convr.weight.data_ptr())
+        if getattr(self, "_zr_key", None) != key:
+            with torch.no_grad():
+                self._zr_w = torch.cat([self.convz.weight, self.convr.weight], dim=0).to(dt)
+                self._zr_b = torch.cat([self.convz.bias, self.convr.bias], dim=0).to(dt)
+            self._zr_key = key
+        return self._zr_w, self._zr_b
+
     def forward(self, h, cz, cr, cq, *x_list):
         C = self.hidden_dim
         hx = torch.cat([h, *x_list], dim=1)                                   # update.py:24-25
         if torch.is_autocast_enabled():           # what autocast would hand the convolutions
-            hx = hx.to(torch.get_autocast_gpu_dtype())
+            hx = hx.to(torch.get_autocast_dtype("cuda"))
         dt = hx.dtype
-        zr = nn.functional.conv2d(hx, torch.cat([self.convz.weight, self.convr.weight], dim=0).to(dt),
-                                  torch.cat([self.convz.bias, self.convr.bias], dim=0).to(dt),
-                                  padding=self.convz.padding)
-        zc, rc = zr[:, :C].contiguous(), zr[:, C:].contiguous()
         h, cz, cr, cq = h.to(dt).contiguous(), cz.to(dt), cr.to(dt), cq.to(dt)
-        if torch.is_grad_enabled() and (zr.requires_grad or h.requires_grad or cr.requires_grad):
-            rhx = torch.cat([gru_gate_r(rc, cr, h), hx[:, C:]], dim=1)       # [r*h, x]  update.py:28-29
-        else:
-            gru_gate_r(rc, cr, h, out=hx[:, :C])  # hx is this call's own copy and both convolutions have read it
-            rhx = hx
-        qc = self.convq(rhx)
-        return gru_update(zc, cz, qc.to(dt), cq, h)                           # update.py:27,29,31
+        train = torch.is_grad_enabled() and (hx.requires_grad or cr.requires_grad or cz.requires_grad
+                                             or cq.requires_grad or self.convz.weight.requires_grad)
+        if train:
+            zr = nn.functional.conv2d(hx, torch.cat([self.convz.weight, self.convr.weight], dim=0).to(dt),
+                                      torch.cat([self.convz.bias, self.convr.bias], dim=0).to(dt),
+                                      padding=self.convz.padding)
+            rhx = torch.cat([gru_gate_r(zr[:, C:], cr, h), hx[:, C:]], dim=1)    # [r*h, x]  update.py:28-29
+            qc = self.convq(rhx)
+            return gru_update(zr[:, :C], cz, qc.to(dt), cq, h)                    # update.py:27,29,31
+        with torch.no_grad():
+            w, b = self._stacked(dt)
+            zr = nn.functional.conv2d(hx, w, b, padding=self.convz.padding)
+            gru_gate_r(zr[:, C:], cr, h, out=hx[:, :C])   # hx is this call's own copy; both convolutions have read it
+            qc = self.convq(hx)
+            return gru_update(zr[:, :C], cz, qc.to(dt), cq, h)
 
 
 class _UpsampleFn(torch.autograd.Function):

@@ -148,6 +148,51 @@ def test_convgru_module_matches_reference(R, golden, case):
     assert rel(h, g["h"]) == 0.0
 
 
+def _torch_convgru(gru, h, cz, cr, cq, *x_list):
+    """The reference's ConvGRU.forward (core/update.py:23-32) spelled with torch ops on the same parameters."""
+    x = torch.cat(x_list, dim=1)
+    hx = torch.cat([h, x], dim=1)
+    z = torch.sigmoid(gru.convz(hx) + cz)
+    r = torch.sigmoid(gru.convr(hx) + cr)
+    q = torch.tanh(gru.convq(torch.cat([r * h, x], dim=1)) + cq)
+    return (1 - z) * h + z * q
+
+
+@pytest.mark.parametrize("amp", [None, torch.float16, torch.bfloat16])
+def test_convgru_module_under_autocast_at_model_size(R, amp):
+    """gru08 of the default model at the KITTI 1/4 resolution (hidden 128, inputs 128 + 128), inference and
+    training, with and without autocast, against the same torch ops.  Under autocast the motion features are
+    fp32 (core/update.py:85 concatenates the fp32 flow) while h and the context are 16-bit."""
+    torch.manual_seed(31)
+    N, C, H, W = 2, 128, 96, 312
+    gru = R.ConvGRUHip(C, 256).cuda()
+    cdt = amp or torch.float32
+    h = torch.tanh(torch.randn(N, C, H, W, device="cuda")).to(cdt)
+    ctx = torch.randn(N, 3 * C, H, W, device="cuda").to(cdt)
+    motion = torch.randn(N, 128, H, W, device="cuda")
+    up = torch.randn(N, 128, H, W, device="cuda").to(cdt)
+    tol = 2e-4 if amp is None else 2 * TOL16[amp]
+    with torch.autocast("cuda", dtype=cdt, enabled=amp is not None):
+        with torch.no_grad():
+            mine = gru(h, *ctx.split(C, dim=1), motion, up)
+            ref = _torch_convgru(gru, h, *ctx.split(C, dim=1), motion, up)
+        assert mine.dtype == ref.dtype
+        assert rel(mine, ref.float().cpu().numpy()) < tol
+    # training: gradients of the parameters and of h (a fresh autocast region: the weight casts cached under
+    # no_grad above carry no autograd history)
+    with torch.autocast("cuda", dtype=cdt, enabled=amp is not None):
+        grads = []
+        gout = torch.randn(N, C, H, W, device="cuda")       # O(1) gradients: nothing underflows in fp16
+        for fn in (gru, lambda *a: _torch_convgru(gru, *a)):
+            gru.zero_grad()
+            hh = h.clone().requires_grad_(True)
+            out = fn(hh, *ctx.split(C, dim=1), motion, up)
+            (out.float() * gout).sum().backward()
+            grads.append([hh.grad.float()] + [p.grad.float().clone() for p in gru.parameters()])
+        for a, b in zip(*grads):
+            assert rel(a, b.cpu().numpy()) < (1e-3 if amp is None else 5e-2)
+
+
 # ------------------------------------------------------------------ 16-bit: per-operation rounding
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("case", GRU_CASES)
@@ -351,4 +396,4 @@ def test_update_argument_errors(R):
     from raft_stereo_amd._lib import lib
     assert lib.rc_upsample_flow_fwd(None, 0, None, None, 1, 1, 1, 1, 4, 0, None) != 0
     assert lib.rc_upsample_flow_fwd(1, 8, 1, 16, 1, 2, 2, 2, 3, 0, None) != 0      # factor 3
-    assert lib.rc_gru_update(None, None, 0, None, None, 0, None, None, 1, 1, 0, None) != 0
+    assert lib.rc_gru_update(None, 0, None, 0, None, 0, None, 0, None, None, 1, 1, 0, None) != 0
