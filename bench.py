@@ -48,9 +48,30 @@ DTYPES = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
 D, LEVELS, RADIUS = 256, 4, 4
 
 
+def synthetic_coords(B, H, W, seed=1234, adversarial=False):
+    """SURVEY 8(d) lookup coordinates: x = w - disp with disp piecewise smooth in [0, W/2] (a bilinearly
+    upsampled 8x8 grid of U(0, W/3) plus U(-0.5, 0.5) noise), or i.i.d. U(0, W) for the adversarial case;
+    y = the row index.  [B, 2, H, W] float32 (numpy)."""
+    rng = np.random.default_rng(seed)
+    f32 = np.float32
+    xs = np.arange(W, dtype=f32)[None, None, :].repeat(B, 0).repeat(H, 1)
+    ys = np.arange(H, dtype=f32)[None, :, None].repeat(B, 0).repeat(W, 2)
+    if adversarial:
+        disp = rng.uniform(0, W, size=(B, H, W)).astype(f32)
+    else:
+        coarse = rng.uniform(0, W / 3, size=(B, 8, 8)).astype(f32)
+        gy, gx = np.linspace(0, 7, H, dtype=f32), np.linspace(0, 7, W, dtype=f32)
+        y0, x0 = np.clip(np.floor(gy).astype(int), 0, 6), np.clip(np.floor(gx).astype(int), 0, 6)
+        fy, fx = (gy - y0)[None, :, None], (gx - x0)[None, None, :]
+        rows0, rows1 = coarse[:, y0], coarse[:, y0 + 1]
+        smooth = (rows0[:, :, x0] * (1 - fy) * (1 - fx) + rows0[:, :, x0 + 1] * (1 - fy) * fx
+                  + rows1[:, :, x0] * fy * (1 - fx) + rows1[:, :, x0 + 1] * fy * fx)
+        disp = np.clip(smooth + rng.uniform(-0.5, 0.5, size=(B, H, W)), 0, W / 2).astype(f32)
+    return np.ascontiguousarray(np.stack([xs - disp, ys], axis=1).astype(f32))
+
+
 def synthetic_inputs(cfg, device, seed):
     """N(0,1) feature maps, piecewise-smooth disparity; all on the GPU before timing."""
-    from oracle.corr_oracle import synthetic_coords   # input generator only (numpy); not the path under test
     g = torch.Generator(device=device).manual_seed(seed)
     B, H, W = cfg["batch"], cfg["H"], cfg["W"]
     f1 = torch.randn((B, D, H, W), generator=g, device=device).to(DTYPES[cfg["dtype"]])
@@ -285,7 +306,6 @@ def update_ops(cfg, device, n=50):
         bias = torch.randn((64,), generator=g, device=device).requires_grad_(True)
         f1 = torch.randn((B, D, H, W), generator=g, device=device).to(dt).requires_grad_(True)
         f2 = torch.randn((B, D, H, W), generator=g, device=device).to(dt).requires_grad_(True)
-        from oracle.corr_oracle import synthetic_coords
         crd = torch.from_numpy(synthetic_coords(B, H, W, seed=5)).to(device)
         gact = torch.randn((B, 64, H, W), generator=g, device=device).to(dt)
 
@@ -395,7 +415,6 @@ def main():
         cfg["dtype"] = args.dtype
     step = Step(cfg, device, seed=1234 + rank)
     if args.adversarial:
-        from oracle.corr_oracle import synthetic_coords
         step.coords = torch.from_numpy(synthetic_coords(cfg["batch"], cfg["H"], cfg["W"], seed=7, adversarial=True)).to(device)
 
     def barrier():

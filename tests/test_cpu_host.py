@@ -138,3 +138,18 @@ def test_two_rank_gloo_sharding(tmp_path):
                          env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert res.stdout.count("ok") == 2
+
+
+def test_bench_input_generator_matches_the_oracles():
+    """bench.py carries its own copy of the synthetic-coordinate generator (only its cpu_baseline leg may touch
+    oracle/); both copies must produce the same workload."""
+    import importlib.util
+    import numpy as np
+    from oracle.corr_oracle import synthetic_coords as ref
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for adv in (False, True):
+        assert np.array_equal(bench.synthetic_coords(2, 9, 40, seed=5, adversarial=adv), ref(2, 9, 40, seed=5, adversarial=adv))
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert src.count("from oracle") == 1 and "oracle.reg_torch" in src       # the cpu_baseline leg only
