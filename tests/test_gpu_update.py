@@ -381,6 +381,46 @@ def test_sequence_loss_on_channel_slices_and_full_size(R):
         R.sequence_loss_hip(bad, gt, valid)
 
 
+def test_update_ops_replay_from_a_hip_graph(R):
+    """No entry point allocates or synchronises, so the pointwise GRU kernels and the upsampling can sit inside a
+    captured GRU loop: the replayed graph gives the eager results."""
+    gen = torch.Generator(device="cuda").manual_seed(41)
+    N, C, H, W = 1, 32, 12, 40
+    ctx = torch.randn((N, 3 * C, H, W), generator=gen, device="cuda").half()
+    cz, cr, cq = ctx.split(C, dim=1)
+    zr = torch.randn((N, 2 * C, H, W), generator=gen, device="cuda").half()
+    qc = torch.randn((N, C, H, W), generator=gen, device="cuda").half()
+    h0 = torch.tanh(torch.randn((N, C, H, W), generator=gen, device="cuda")).half()
+    flow = torch.randn((N, 2, H, W), generator=gen, device="cuda")
+    mask = torch.randn((N, 9 * 16, H, W), generator=gen, device="cuda").half()
+
+    def loop():
+        h, outs = h0, []
+        for _ in range(3):
+            buf = torch.cat([h, h], dim=1)
+            R.gru_gate_r(zr[:, C:], cr, h, out=buf[:, :C])
+            h = R.gru_update(zr[:, :C], cz, qc, cq, h)
+            outs += [buf, h]
+        outs.append(R.upsample_flow_hip(flow, mask, 2, channels=1))
+        return outs
+
+    with torch.no_grad():
+        eager = [o.clone() for o in loop()]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            loop()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            captured = loop()
+        for o in captured:
+            o.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(captured, eager))
+
+
 def test_update_argument_errors(R):
     h = torch.zeros(1, 4, 2, 2)
     with pytest.raises(RuntimeError):
