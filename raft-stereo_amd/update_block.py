@@ -1,0 +1,99 @@
+"""The caller on the far side of the correlation lookup: the multi-scale update block, wired from this
+package's kernels (core/update.py:64-138 of the reference).
+
+    BasicMultiUpdateBlockHip(args, hidden_dims)     same constructor and parameter names as
+                                                    BasicMultiUpdateBlock (a reference state_dict loads as is)
+        .forward(net, inp, corr=None, flow=None, iter08=True, iter16=True, iter32=True, update=True,
+                 corr_fn=None, coords=None)
+
+What runs in the HIP library: the three ConvGRUs' gate arithmetic (ConvGRUHip) and, when the caller hands
+over the correlation block and the coordinates instead of a looked-up `corr` tensor, the lookup fused with
+the motion encoder's first layer (`corr_fn.lookup_convc1`).  The dense convolutions, the pooling and the
+bilinear resizing between scales are torch's, as in the reference.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from raft_stereo_amd.update import ConvGRUHip
+
+
+def _down2(x):
+    return F.avg_pool2d(x, 3, stride=2, padding=1)                      # update.py:87-88
+
+
+def _resize_like(x, ref):
+    return F.interpolate(x, ref.shape[2:], mode="bilinear", align_corners=True)   # update.py:93-95
+
+
+class MotionEncoderHip(nn.Module):
+    """core/update.py:64-85.  `forward(flow, corr)` as the reference; `forward(flow, corr_fn=..., coords=...)`
+    never materialises the L*(2r+1)-channel lookup result."""
+
+    def __init__(self, args):
+        super().__init__()
+        planes = args.corr_levels * (2 * args.corr_radius + 1)
+        self.convc1 = nn.Conv2d(planes, 64, 1)
+        self.convc2 = nn.Conv2d(64, 64, 3, padding=1)
+        self.convf1 = nn.Conv2d(2, 64, 7, padding=3)
+        self.convf2 = nn.Conv2d(64, 64, 3, padding=1)
+        self.conv = nn.Conv2d(128, 126, 3, padding=1)
+
+    def forward(self, flow, corr=None, corr_fn=None, coords=None):
+        if corr is None:
+            if corr_fn is None or coords is None:
+                raise ValueError("pass either corr or (corr_fn, coords)")
+            c = corr_fn.lookup_convc1(coords, self.convc1.weight, self.convc1.bias)
+        else:
+            c = F.relu(self.convc1(corr))
+        c = F.relu(self.convc2(c))
+        f = F.relu(self.convf2(F.relu(self.convf1(flow))))
+        both = F.relu(self.conv(torch.cat([c, f.to(c.dtype)], dim=1)))
+        return torch.cat([both, flow], dim=1)
+
+
+class FlowHeadHip(nn.Module):
+    """core/update.py:6-14 (two convolutions; nothing pointwise worth a kernel)."""
+
+    def __init__(self, input_dim=128, hidden_dim=256, output_dim=2):
+        super().__init__()
+        self.conv1 = nn.Conv2d(input_dim, hidden_dim, 3, padding=1)
+        self.conv2 = nn.Conv2d(hidden_dim, output_dim, 3, padding=1)
+
+    def forward(self, x):
+        return self.conv2(F.relu(self.conv1(x)))
+
+
+class BasicMultiUpdateBlockHip(nn.Module):
+    """core/update.py:97-138 with ConvGRUHip at the three scales."""
+
+    def __init__(self, args, hidden_dims=()):
+        super().__init__()
+        self.args = args
+        layers = args.n_gru_layers
+        self.encoder = MotionEncoderHip(args)
+        self.gru08 = ConvGRUHip(hidden_dims[2], 128 + hidden_dims[1] * (layers > 1))
+        self.gru16 = ConvGRUHip(hidden_dims[1], hidden_dims[0] * (layers == 3) + hidden_dims[2])
+        self.gru32 = ConvGRUHip(hidden_dims[0], hidden_dims[1])
+        self.flow_head = FlowHeadHip(hidden_dims[2], hidden_dim=256, output_dim=2)
+        f = 2 ** args.n_downsample
+        self.mask = nn.Sequential(nn.Conv2d(hidden_dims[2], 256, 3, padding=1), nn.ReLU(inplace=True),
+                                  nn.Conv2d(256, f * f * 9, 1, padding=0))
+
+    def forward(self, net, inp, corr=None, flow=None, iter08=True, iter16=True, iter32=True, update=True,
+                corr_fn=None, coords=None):
+        layers = self.args.n_gru_layers
+        if iter32:
+            net[2] = self.gru32(net[2], *inp[2], _down2(net[1]))
+        if iter16:
+            extra = [_down2(net[0])] + ([_resize_like(net[2], net[1])] if layers > 2 else [])
+            net[1] = self.gru16(net[1], *inp[1], *extra)
+        if iter08:
+            motion = self.encoder(flow, corr, corr_fn=corr_fn, coords=coords)
+            extra = [motion] + ([_resize_like(net[1], net[0])] if layers > 1 else [])
+            net[0] = self.gru08(net[0], *inp[0], *extra)
+        if not update:
+            return net
+        delta_flow = self.flow_head(net[0])
+        mask = .25 * self.mask(net[0])             # scaled to balance gradients (update.py:136-137)
+        return net, mask, delta_flow
