@@ -44,6 +44,8 @@ class MotionEncoderHip(nn.Module):
             if corr_fn is None or coords is None:
                 raise ValueError("pass either corr or (corr_fn, coords)")
             c = corr_fn.lookup_convc1(coords, self.convc1.weight, self.convc1.bias)
+            if not torch.is_autocast_enabled():       # a 16-bit pyramid under an fp32 update block
+                c = c.to(self.convc2.weight.dtype)
         else:
             c = F.relu(self.convc1(corr))
         c = F.relu(self.convc2(c))
