@@ -330,6 +330,68 @@ def update_ops(cfg, device, n=50):
                 gru_update_bwd_us=round(t_upd_bwd, 2))
 
 
+def refine_loop(step, cfg, device, reps=3):
+    """Everything RAFTStereo.forward does after its encoders (core/raft_stereo.py:100-141) on this package's
+    operators, beside the contract's metric: correlation block + default-width update block (hidden 128, 3 GRU
+    layers; its dense convolutions are torch's) + convex upsampling, test mode, autocast for 16-bit feature maps.
+    Random-init weights, synthetic context tensors.  Wall clock, synchronised."""
+    from argparse import Namespace
+    import raft_stereo_amd as R
+    B, H, W = cfg["batch"], cfg["H"], cfg["W"]
+    nd = 3 if W * 8 <= 640 else 2
+    dt = DTYPES[cfg["dtype"]]
+    amp = dt != torch.float32
+    realtime = nd == 3        # BASELINE config 2: n_downsample 3, 2 GRU layers, slow_fast_gru; else the defaults
+    args = Namespace(hidden_dims=[128] * 3, corr_levels=LEVELS, corr_radius=RADIUS, n_downsample=nd,
+                     slow_fast_gru=realtime, n_gru_layers=2 if realtime else 3, mixed_precision=amp)
+    g = torch.Generator(device=device).manual_seed(5)
+    blk = R.BasicMultiUpdateBlockHip(args, hidden_dims=args.hidden_dims).to(device).eval()
+    sizes = [(H, W), ((H + 1) // 2, (W + 1) // 2), ((H + 3) // 4, (W + 3) // 4)]
+    net = [torch.tanh(torch.randn((B, 128, h, w), generator=g, device=device)).to(dt) for h, w in sizes]
+    inp = [list(torch.randn((B, 384, h, w), generator=g, device=device).to(dt).split(128, dim=1)) for h, w in sizes]
+    iters = cfg["iters"]
+
+    def once():
+        corr_fn = step.cls(step.f1, step.f2, num_levels=LEVELS, radius=RADIUS)
+        return R.refine_disparity(blk, corr_fn, net, inp, args, iters=iters, test_mode=True)
+
+    with torch.no_grad():
+        once()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            once()
+        torch.cuda.synchronize()
+        dt_s = (time.perf_counter() - t0) / reps
+    out = dict(refine_loop_config=f"{args.n_gru_layers} GRU layers, slow_fast_gru={args.slow_fast_gru}, hidden 128, "
+                                  f"{iters} iterations, 1/{2 ** nd} resolution, autocast={amp}",
+               refine_loop_ms=round(dt_s * 1e3, 2), refine_loop_pairs_per_s=round(B / dt_s, 2),
+               refine_loop_ms_per_iteration=round(dt_s * 1e3 / iters, 3))
+    # the same loop captured once in a HIP graph and replayed (nothing in it allocates outside torch's graph
+    # pool or synchronises): what a latency-bound caller (the realtime configuration) pays per pair
+    try:
+        with torch.no_grad():
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                once()
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                once()
+            graph.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                graph.replay()
+            torch.cuda.synchronize()
+            out["refine_loop_hip_graph_ms"] = round((time.perf_counter() - t0) / reps * 1e3, 2)
+    except Exception as e:      # a side metric must not take the contract's line down
+        out["refine_loop_hip_graph_ms"] = None
+        out["refine_loop_hip_graph_error"] = str(e)[:120]
+    return out
+
+
 def hip_graph_step(step, n=50):
     """The same step (build/prepare + lookups) captured once in a HIP graph and replayed: what a
     caller that captures its GRU loop pays per pair batch once launch overhead is gone.  Reported
@@ -475,6 +537,8 @@ def main():
         extra.update(fused_convc1(step, cfg, device))      # after the timed region: not part of `value`
     if rank == 0 and cfg["H"] * cfg["W"] * cfg["batch"] <= 300000:
         extra.update(update_ops(cfg, device))              # side metrics, after the timed region
+    if not cfg["train"] and rank == 0 and cfg["H"] * cfg["W"] * cfg["batch"] <= 300000:
+        extra.update(refine_loop(step, cfg, device))
     if not cfg["train"] and world == 1:       # side metric; kept out of multi-rank runs (no capture beside RCCL)
         extra.update(hip_graph_step(step))
 
