@@ -279,6 +279,18 @@ int rc_gru_gate_r_bwd(const void* convr_out, const void* cr, int64_t cr_batch_st
                       void* stream);
 
 /*
+ * The glue between the GRU scales (core/update.py:87-95, run every iteration): pool2x(x) =
+ * avg_pool2d(x, 3, stride=2, padding=1) -> [N, C, (H-1)/2+1, (W-1)/2+1] (padding counted: always / 9), and
+ * interp(x, dest) = bilinear resize to Ho x Wo with align_corners=True.  x: [N,C,H,W] contiguous of `dtype`;
+ * out: images out_batch_stride elements apart (a channel slice of the GRU's input buffer works); fp32
+ * arithmetic, result rounded to `dtype`.  Forward only (the update block keeps torch's ops when it trains).
+ */
+int rc_pool2x(const void* x, void* out, int64_t N, int64_t C, int64_t H, int64_t W,
+              int64_t out_batch_stride, int dtype, void* stream);
+int rc_interp_bilinear(const void* x, void* out, int64_t N, int64_t C, int64_t H, int64_t W,
+                       int64_t Ho, int64_t Wo, int64_t out_batch_stride, int dtype, void* stream);
+
+/*
  * SURVEY.md section 8(f) rank 4 -- convex upsampling, RAFTStereo.upsample_flow (core/raft_stereo.py:55-67):
  *     out[n, c, f*h + fy, f*w + fx] = sum_k softmax_k(mask[n, k, fy, fx, h, w]) * f * flow[n, c, h + k/3 - 1, w + k%3 - 1]
  * (zeros outside the image, F.unfold padding=1).  flow: float [N, >=channels, H, W], the first `channels`

@@ -13,6 +13,7 @@ tree, which is NOT shipped):
   gru_gate_r_bwd    autograd of the same lines
   upsample_flow     core/raft_stereo.py:55-67 softmax over 9, unfold(factor*flow, 3x3, padding=1), sum, permute
   upsample_flow_bwd autograd of the same lines
+  pool2x, interp    core/update.py:87-95      3x3 stride-2 mean; bilinear resize, align_corners=True
   sequence_loss     train_stereo.py:35-70     masked L1 over all predictions, EPE metrics, and its gradient
 
 Parity pin: tests/test_oracle_golden.py checks these against vectors captured from the reference's own
@@ -148,6 +149,36 @@ def sequence_loss(flow_preds, flow_gt, valid, loss_gamma=0.9, max_flow=700):
     metrics = {"epe": float(epe.mean()), "1px": float((epe < 1).mean()), "3px": float((epe < 3).mean()),
                "5px": float((epe < 5).mean())}
     return loss, metrics, grads
+
+
+def pool2x(x):
+    """avg_pool2d(x, 3, stride=2, padding=1), padding counted in the mean   (core/update.py:87-88)."""
+    x = np.asarray(x, dtype=np.float64)
+    N, C, H, W = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    pad = np.zeros((N, C, 2 * Ho + 1, 2 * Wo + 1))
+    pad[:, :, 1:H + 1, 1:W + 1] = x
+    out = np.zeros((N, C, Ho, Wo))
+    for dy in range(3):
+        for dx in range(3):
+            out += pad[:, :, dy:dy + 2 * Ho:2, dx:dx + 2 * Wo:2]
+    return (out / 9.0).astype(F32)
+
+
+def interp(x, Ho, Wo):
+    """F.interpolate(x, (Ho, Wo), mode='bilinear', align_corners=True)   (core/update.py:93-95)."""
+    x = np.asarray(x, dtype=np.float64)
+    H, W = x.shape[2:]
+    # torch computes the source positions in fp32: scale = (in-1)/(out-1), position = scale * index
+    sy = F32(H - 1) / F32(Ho - 1) if Ho > 1 else F32(0)
+    sx = F32(W - 1) / F32(Wo - 1) if Wo > 1 else F32(0)
+    fy, fx = (sy * np.arange(Ho, dtype=F32)).astype(F32), (sx * np.arange(Wo, dtype=F32)).astype(F32)
+    y0, x0 = np.minimum(fy.astype(int), H - 1), np.minimum(fx.astype(int), W - 1)
+    y1, x1 = np.minimum(y0 + 1, H - 1), np.minimum(x0 + 1, W - 1)
+    ly, lx = (fy - y0.astype(F32)).astype(np.float64)[:, None], (fx - x0.astype(F32)).astype(np.float64)[None, :]
+    top = x[:, :, y0][:, :, :, x0] * (1 - lx) + x[:, :, y0][:, :, :, x1] * lx
+    bot = x[:, :, y1][:, :, :, x0] * (1 - lx) + x[:, :, y1][:, :, :, x1] * lx
+    return (top * (1 - ly) + bot * ly).astype(F32)
 
 
 def rel_to_max(a, b):

@@ -924,3 +924,98 @@ extern "C" int rc_sequence_loss_bwd(const float* const* preds, float* const* gra
                      HW, total);
   return rc_check_launch("rc_sequence_loss_bwd");
 }
+
+// ------------------------------------------------------------------------ between-scale glue
+// core/update.py:87-95: pool2x = avg_pool2d(x, 3, stride=2, padding=1) (count_include_pad: always / 9) feeds the
+// coarser GRU, interp = bilinear resize with align_corners=True feeds the finer one.  Streaming kernels, one
+// output element per thread along W (coalesced), fp32 arithmetic, result rounded to the tensor type; the output
+// may be a channel slice of the buffer the GRU's convolutions read (batch stride argument).
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(PW_THREADS) void pool2x_kernel(const T* __restrict__ x, T* __restrict__ out, int H, int W,
+                                                            int Ho, int Wo, int C, int64_t out_bs) {
+  const int wo = blockIdx.x * PW_THREADS + threadIdx.x;
+  if (wo >= Wo) return;
+  const int ho = blockIdx.y % Ho;
+  const int64_t nc = blockIdx.y / Ho;      // n*C + c
+  const int64_t n = nc / C, c = nc - n * C;
+  const T* src = x + nc * (int64_t)H * W;
+  float acc = 0.f;
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy) {
+    const int h = 2 * ho + dy;
+    if ((unsigned)h >= (unsigned)H) continue;   // block-uniform
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int w = 2 * wo + dx;
+      if ((unsigned)w < (unsigned)W) acc += rc_to_float(src[(int64_t)h * W + w]);
+    }
+  }
+  out[n * out_bs + (c * Ho + ho) * (int64_t)Wo + wo] = rc_from_float<T>(acc * (1.0f / 9.0f));
+}
+
+template <typename T>
+__global__ __launch_bounds__(PW_THREADS) void interp_kernel(const T* __restrict__ x, T* __restrict__ out, int H, int W,
+                                                            int Ho, int Wo, int C, int64_t out_bs, float sy, float sx) {
+  const int wo = blockIdx.x * PW_THREADS + threadIdx.x;
+  if (wo >= Wo) return;
+  const int ho = blockIdx.y % Ho;
+  const int64_t nc = blockIdx.y / Ho;
+  const int64_t n = nc / C, c = nc - n * C;
+  // align_corners=True: source position = destination index * (in - 1) / (out - 1)
+  const float fy = sy * (float)ho, fx = sx * (float)wo;
+  const int y0 = min((int)fy, H - 1), x0 = min((int)fx, W - 1);
+  const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+  const float ly = fy - (float)y0, lx = fx - (float)x0;
+  const T* src = x + nc * (int64_t)H * W;
+  const float v00 = rc_to_float(src[(int64_t)y0 * W + x0]), v01 = rc_to_float(src[(int64_t)y0 * W + x1]);
+  const float v10 = rc_to_float(src[(int64_t)y1 * W + x0]), v11 = rc_to_float(src[(int64_t)y1 * W + x1]);
+  const float hy = 1.0f - ly, hx = 1.0f - lx;
+  const float v = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+  out[n * out_bs + (c * Ho + ho) * (int64_t)Wo + wo] = rc_from_float<T>(v);
+}
+
+template <typename T>
+int launch_resample(int which, const void* x, void* out, int64_t N, int64_t C, int64_t H, int64_t W, int64_t Ho,
+                    int64_t Wo, int64_t out_bs, hipStream_t st) {
+  const dim3 grid((unsigned)((Wo + PW_THREADS - 1) / PW_THREADS), (unsigned)(N * C * Ho));
+  if (which == 0) {
+    hipLaunchKernelGGL((pool2x_kernel<T>), grid, dim3(PW_THREADS), 0, st, (const T*)x, (T*)out, (int)H, (int)W, (int)Ho,
+                       (int)Wo, (int)C, out_bs);
+    return rc_check_launch("rc_pool2x");
+  }
+  const float sy = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, sx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+  hipLaunchKernelGGL((interp_kernel<T>), grid, dim3(PW_THREADS), 0, st, (const T*)x, (T*)out, (int)H, (int)W, (int)Ho,
+                     (int)Wo, (int)C, out_bs, sy, sx);
+  return rc_check_launch("rc_interp_bilinear");
+}
+
+int resample_any(int which, const void* x, void* out, int64_t N, int64_t C, int64_t H, int64_t W, int64_t Ho,
+                 int64_t Wo, int64_t out_bs, int dtype, void* stream) {
+  RC_REQUIRE(x && out, RC_EINVAL, "null pointer argument");
+  RC_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && H < (1 << 24) && W < (1 << 24), RC_EINVAL,
+             "bad sizes");
+  RC_REQUIRE(N * C * Ho < (1ll << 31), RC_EINVAL, "too many rows");
+  RC_REQUIRE(out_bs >= C * Ho * Wo, RC_EINVAL, "output batch stride shorter than one image");
+  hipStream_t st = (hipStream_t)stream;
+  switch (dtype) {
+    case RC_F32: return launch_resample<float>(which, x, out, N, C, H, W, Ho, Wo, out_bs, st);
+    case RC_F16: return launch_resample<rc_half>(which, x, out, N, C, H, W, Ho, Wo, out_bs, st);
+    case RC_BF16: return launch_resample<rc_bf16>(which, x, out, N, C, H, W, Ho, Wo, out_bs, st);
+  }
+  rc_set_error("unknown dtype %d", dtype);
+  return RC_EUNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" int rc_pool2x(const void* x, void* out, int64_t N, int64_t C, int64_t H, int64_t W,
+                         int64_t out_batch_stride, int dtype, void* stream) {
+  return resample_any(0, x, out, N, C, H, W, (H - 1) / 2 + 1, (W - 1) / 2 + 1, out_batch_stride, dtype, stream);
+}
+
+extern "C" int rc_interp_bilinear(const void* x, void* out, int64_t N, int64_t C, int64_t H, int64_t W, int64_t Ho,
+                                  int64_t Wo, int64_t out_batch_stride, int dtype, void* stream) {
+  return resample_any(1, x, out, N, C, H, W, Ho, Wo, out_batch_stride, dtype, stream);
+}

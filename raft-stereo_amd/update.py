@@ -197,6 +197,38 @@ class ConvGRUHip(nn.Module):
             return gru_update(zr[:, :C], cz, qc.to(dt), cq, h)
 
 
+def _resample_ok(x):
+    return x.is_cuda and x.dim() == 4 and x.dtype in _DT and not (torch.is_grad_enabled() and x.requires_grad)
+
+
+def pool2x_hip(x):
+    """`F.avg_pool2d(x, 3, stride=2, padding=1)` (core/update.py:87-88) in the library.  Forward only."""
+    if not _resample_ok(x):
+        raise RuntimeError("pool2x_hip needs a GPU [N,C,H,W] tensor outside autograd")
+    x = x.contiguous()
+    N, C, H, W = x.shape
+    out = torch.empty((N, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=x.dtype, device=x.device)
+    with _on_device(x.device):
+        check(lib.rc_pool2x(x.data_ptr(), out.data_ptr(), N, C, H, W, out[0].numel(), _DT[x.dtype],
+                            _stream(x.device)), "rc_pool2x")
+    return out
+
+
+def interp_hip(x, dest):
+    """`F.interpolate(x, dest.shape[2:], mode='bilinear', align_corners=True)` (core/update.py:93-95) in the
+    library, in x's own type (fp32 arithmetic).  Forward only."""
+    if not _resample_ok(x):
+        raise RuntimeError("interp_hip needs a GPU [N,C,H,W] tensor outside autograd")
+    x = x.contiguous()
+    N, C, H, W = x.shape
+    Ho, Wo = int(dest.shape[2]), int(dest.shape[3])
+    out = torch.empty((N, C, Ho, Wo), dtype=x.dtype, device=x.device)
+    with _on_device(x.device):
+        check(lib.rc_interp_bilinear(x.data_ptr(), out.data_ptr(), N, C, H, W, Ho, Wo, out[0].numel(), _DT[x.dtype],
+                                     _stream(x.device)), "rc_interp_bilinear")
+    return out
+
+
 class _UpsampleFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, flow, mask, f, C):

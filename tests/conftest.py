@@ -16,6 +16,7 @@ MODEL_CASE = "model_b1_h24_w32"
 CONVC1_CASES = [n[len("convc1_"):] for n in _NPZ if n.startswith("convc1_")]
 # the reference's ConvGRU and upsample_flow (make_golden_update.py)
 GRU_CASES = [n for n in _NPZ if n.startswith("update_gru_")]
+RESAMPLE_CASE = "update_resample"
 UPSAMPLE_CASES = [n for n in _NPZ if n.startswith("update_up_")]
 # the reference's BasicMultiUpdateBlock on its own CorrBlock1D lookup (make_golden_block.py)
 BLOCK_CASE = "block_l3_h16"

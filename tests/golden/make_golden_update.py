@@ -15,6 +15,8 @@ checked apart from the convolutions.  A random grad_out is back-propagated throu
 upsample_flow (core/raft_stereo.py:55-67): the method is called unbound on a stand-in `self` that only
 carries `args.n_downsample`; fp32 masks for factors 2, 4, 8 and one fp16 mask (the autocast case).
 
+pool2x / interp (core/update.py:87-95): the reference's two helper functions on odd and even sizes.
+
 Only data is stored, in `update_*.npz`.
 """
 import os
@@ -29,7 +31,7 @@ REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
 sys.dont_write_bytecode = True
 sys.path.insert(0, REF)
 sys.modules.setdefault("opt_einsum", types.SimpleNamespace(contract=None))
-from core.update import ConvGRU  # noqa: E402
+from core.update import ConvGRU, pool2x, interp  # noqa: E402
 from core.raft_stereo import RAFTStereo  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -101,8 +103,26 @@ def run_up(name, N, D, H, W, nd, seed):
     return rec
 
 
+def run_resample(seed):
+    """pool2x / interp of core/update.py:87-95 on odd and even sizes."""
+    torch.manual_seed(seed)
+    rec = {}
+    for i, shp in enumerate([(2, 5, 7, 9), (1, 3, 8, 12), (1, 2, 1, 5), (1, 4, 12, 80)]):
+        x = torch.randn(shp)
+        rec[f"pool_in{i}"], rec[f"pool_out{i}"] = x, pool2x(x)
+    for i, (shp, dst) in enumerate([((1, 3, 4, 6), (8, 12)), ((2, 5, 4, 5), (7, 9)), ((1, 2, 3, 3), (3, 3)),
+                                    ((1, 4, 6, 40), (12, 80)), ((1, 2, 2, 2), (1, 5))]):
+        x = torch.randn(shp)
+        rec[f"interp_in{i}"], rec[f"interp_out{i}"] = x, interp(x, torch.empty(1, 1, *dst))
+    return {k: v.numpy().copy() for k, v in rec.items()}
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
+    rec = run_resample(400)
+    path = os.path.join(HERE, "update_resample.npz")
+    np.savez_compressed(path, **rec)
+    print("resample", {k: v.shape for k, v in rec.items() if "out" in k}, os.path.getsize(path) // 1024, "KiB")
     for n, case in enumerate(GRU_CASES):
         rec = run_gru(*case, seed=100 + n)
         path = os.path.join(HERE, "update_" + case[0] + ".npz")

@@ -381,6 +381,40 @@ def test_sequence_loss_on_channel_slices_and_full_size(R):
         R.sequence_loss_hip(bad, gt, valid)
 
 
+# ------------------------------------------------------------------ between-scale glue
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_pool2x_and_interp_match_reference(R, golden, dtype):
+    g = golden("update_resample")
+    tol = TOL32 if dtype == torch.float32 else TOL16[dtype]
+    rd = (lambda a: a) if dtype == torch.float32 else _rounder(dtype)
+    with torch.no_grad():
+        for k in [k for k in g if k.startswith("pool_in")]:
+            ref = g["pool_out" + k[len("pool_in"):]] if dtype == torch.float32 else U.pool2x(rd(g[k]))
+            out = R.pool2x_hip(dev(g[k], dtype))
+            assert out.dtype == dtype and tuple(out.shape) == ref.shape
+            assert rel(out, ref) < tol, k
+        for k in [k for k in g if k.startswith("interp_in")]:
+            gold = g["interp_out" + k[len("interp_in"):]]
+            ref = gold if dtype == torch.float32 else U.interp(rd(g[k]), *gold.shape[2:])
+            out = R.interp_hip(dev(g[k], dtype), torch.empty(1, 1, *gold.shape[2:]))
+            assert out.dtype == dtype and tuple(out.shape) == ref.shape
+            assert rel(out, ref) < tol, k
+
+
+def test_pool2x_and_interp_equal_torch_at_model_size(R):
+    """net[0] -> 1/8 resolution and net[1] -> 1/4 resolution of the KITTI share, against torch's own kernels."""
+    torch.manual_seed(12)
+    with torch.no_grad():
+        for dtype in (torch.float32, torch.float16):
+            hi = torch.randn(8, 128, 96, 312, device="cuda").to(dtype)
+            lo = torch.randn(8, 128, 48, 156, device="cuda").to(dtype)
+            tol = TOL32 if dtype == torch.float32 else TOL16[dtype]
+            ref = torch.nn.functional.avg_pool2d(hi.float(), 3, stride=2, padding=1)
+            assert rel(R.pool2x_hip(hi), ref.cpu().numpy()) < tol
+            ref = torch.nn.functional.interpolate(lo.float(), (96, 312), mode="bilinear", align_corners=True)
+            assert rel(R.interp_hip(lo, hi), ref.cpu().numpy()) < tol
+
+
 def test_update_ops_replay_from_a_hip_graph(R):
     """No entry point allocates or synchronises, so the pointwise GRU kernels and the upsampling can sit inside a
     captured GRU loop: the replayed graph gives the eager results."""

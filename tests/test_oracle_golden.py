@@ -225,3 +225,12 @@ def test_sequence_loss_matches_reference(golden, case):
         assert abs(metrics[m] - float(g["metrics"][k])) <= 1e-5
     for i in range(n):
         assert U.rel_to_max(grads[i], g[f"d_pred_{i}"]) <= 1e-5
+
+
+def test_pool2x_and_interp_match_reference(golden):
+    g = golden("update_resample")
+    for k in [k for k in g if k.startswith("pool_in")]:
+        assert U.rel_to_max(U.pool2x(g[k]), g["pool_out" + k[len("pool_in"):]]) <= 1e-6, k
+    for k in [k for k in g if k.startswith("interp_in")]:
+        ref = g["interp_out" + k[len("interp_in"):]]
+        assert U.rel_to_max(U.interp(g[k], *ref.shape[2:]), ref) <= 1e-6, k
