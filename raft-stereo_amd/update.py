@@ -175,10 +175,15 @@ class ConvGRUHip(nn.Module):
 
     def forward(self, h, cz, cr, cq, *x_list):
         C = self.hidden_dim
-        hx = torch.cat([h, *x_list], dim=1)                                   # update.py:24-25
         if torch.is_autocast_enabled():           # what autocast would hand the convolutions
-            hx = hx.to(torch.get_autocast_dtype("cuda"))
-        dt = hx.dtype
+            dt = torch.get_autocast_dtype("cuda")
+        else:
+            dt = h.dtype
+            for t in x_list:
+                dt = torch.promote_types(dt, t.dtype)
+        # update.py:24-25; operands are cast BEFORE the concatenation (same values, and a fp32 member -- the motion
+        # features carry the fp32 flow, update.py:85 -- no longer drags the whole buffer through fp32)
+        hx = torch.cat([t.to(dt) for t in (h, *x_list)], dim=1)
         h, cz, cr, cq = h.to(dt).contiguous(), cz.to(dt), cr.to(dt), cq.to(dt)
         train = torch.is_grad_enabled() and (hx.requires_grad or cr.requires_grad or cz.requires_grad
                                              or cq.requires_grad or self.convz.weight.requires_grad)

@@ -55,7 +55,9 @@ class MotionEncoderHip(nn.Module):
         c = F.relu(self.convc2(c))
         f = F.relu(self.convf2(F.relu(self.convf1(flow))))
         both = F.relu(self.conv(torch.cat([c, f.to(c.dtype)], dim=1)))
-        return torch.cat([both, flow], dim=1)
+        # under autocast the reference's concatenation promotes to fp32 and the GRU's convolutions cast back;
+        # casting the two flow planes instead gives the same values without the fp32 round trip of 126 planes
+        return torch.cat([both, flow.to(both.dtype) if torch.is_autocast_enabled() else flow], dim=1)
 
 
 class FlowHeadHip(nn.Module):
