@@ -932,62 +932,98 @@ extern "C" int rc_sequence_loss_bwd(const float* const* preds, float* const* gra
 // may be a channel slice of the buffer the GRU's convolutions read (batch stride argument).
 namespace {
 
-template <typename T>
+// One thread = VEC consecutive outputs of one output row (VEC * sizeof(T) = 16 bytes when rows are whole
+// vectors, else 1): a flat index over all output vectors keeps every block full whatever the row length.
+template <typename T, int VEC>
 __global__ __launch_bounds__(PW_THREADS) void pool2x_kernel(const T* __restrict__ x, T* __restrict__ out, int H, int W,
-                                                            int Ho, int Wo, int C, int64_t out_bs) {
-  const int wo = blockIdx.x * PW_THREADS + threadIdx.x;
-  if (wo >= Wo) return;
-  const int ho = blockIdx.y % Ho;
-  const int64_t nc = blockIdx.y / Ho;      // n*C + c
-  const int64_t n = nc / C, c = nc - n * C;
+                                                            int Ho, int Wo, int C, int64_t out_bs, int64_t total) {
+  const int64_t v = (int64_t)blockIdx.x * PW_THREADS + threadIdx.x;
+  if (v >= total) return;
+  const int wv = Wo / VEC;
+  const int wo0 = (int)(v % wv) * VEC;
+  const int64_t r = v / wv;
+  const int ho = (int)(r % Ho);
+  const int64_t nc = r / Ho, n = nc / C, c = nc - n * C;
   const T* src = x + nc * (int64_t)H * W;
-  float acc = 0.f;
+  float acc[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
 #pragma unroll
   for (int dy = -1; dy <= 1; ++dy) {
     const int h = 2 * ho + dy;
-    if ((unsigned)h >= (unsigned)H) continue;   // block-uniform
+    if ((unsigned)h >= (unsigned)H) continue;
+    const T* row = src + (int64_t)h * W;
+    // the 2 VEC + 1 inputs under this thread's outputs: columns 2 wo0 - 1 .. 2 wo0 + 2 VEC - 1
+    float in[2 * VEC + 1];
 #pragma unroll
-    for (int dx = -1; dx <= 1; ++dx) {
-      const int w = 2 * wo + dx;
-      if ((unsigned)w < (unsigned)W) acc += rc_to_float(src[(int64_t)h * W + w]);
+    for (int q = 0; q < 2 * VEC + 1; ++q) {
+      const int w = 2 * wo0 - 1 + q;
+      in[q] = (unsigned)w < (unsigned)W ? rc_to_float(row[w]) : 0.f;
     }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] += (in[2 * j] + in[2 * j + 1]) + in[2 * j + 2];
   }
-  out[n * out_bs + (c * Ho + ho) * (int64_t)Wo + wo] = rc_from_float<T>(acc * (1.0f / 9.0f));
+  typename pw_vec<T, VEC>::type o;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) o[j] = rc_from_float<T>(acc[j] * (1.0f / 9.0f));
+  *reinterpret_cast<typename pw_vec<T, VEC>::type*>(out + n * out_bs + (c * Ho + ho) * (int64_t)Wo + wo0) = o;
 }
 
-template <typename T>
+template <typename T, int VEC>
 __global__ __launch_bounds__(PW_THREADS) void interp_kernel(const T* __restrict__ x, T* __restrict__ out, int H, int W,
-                                                            int Ho, int Wo, int C, int64_t out_bs, float sy, float sx) {
-  const int wo = blockIdx.x * PW_THREADS + threadIdx.x;
-  if (wo >= Wo) return;
-  const int ho = blockIdx.y % Ho;
-  const int64_t nc = blockIdx.y / Ho;
-  const int64_t n = nc / C, c = nc - n * C;
-  // align_corners=True: source position = destination index * (in - 1) / (out - 1)
-  const float fy = sy * (float)ho, fx = sx * (float)wo;
-  const int y0 = min((int)fy, H - 1), x0 = min((int)fx, W - 1);
-  const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
-  const float ly = fy - (float)y0, lx = fx - (float)x0;
-  const T* src = x + nc * (int64_t)H * W;
-  const float v00 = rc_to_float(src[(int64_t)y0 * W + x0]), v01 = rc_to_float(src[(int64_t)y0 * W + x1]);
-  const float v10 = rc_to_float(src[(int64_t)y1 * W + x0]), v11 = rc_to_float(src[(int64_t)y1 * W + x1]);
-  const float hy = 1.0f - ly, hx = 1.0f - lx;
-  const float v = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
-  out[n * out_bs + (c * Ho + ho) * (int64_t)Wo + wo] = rc_from_float<T>(v);
+                                                            int Ho, int Wo, int C, int64_t out_bs, float sy, float sx,
+                                                            int64_t total) {
+  const int64_t v = (int64_t)blockIdx.x * PW_THREADS + threadIdx.x;
+  if (v >= total) return;
+  const int wv = Wo / VEC;
+  const int wo0 = (int)(v % wv) * VEC;
+  const int64_t r = v / wv;
+  const int ho = (int)(r % Ho);
+  const int64_t nc = r / Ho, n = nc / C, c = nc - n * C;
+  // align_corners=True: source position = destination index * (in - 1) / (out - 1), in fp32 like torch
+  const float fy = sy * (float)ho;
+  const int y0 = min((int)fy, H - 1), y1 = min(y0 + 1, H - 1);
+  const float ly = fy - (float)y0, hy = 1.0f - ly;
+  const T* r0 = x + nc * (int64_t)H * W + (int64_t)y0 * W;
+  const T* r1 = x + nc * (int64_t)H * W + (int64_t)y1 * W;
+  typename pw_vec<T, VEC>::type o;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    const float fx = sx * (float)(wo0 + j);
+    const int x0 = min((int)fx, W - 1), x1 = min(x0 + 1, W - 1);
+    const float lx = fx - (float)x0, hx = 1.0f - lx;
+    const float top = hx * rc_to_float(r0[x0]) + lx * rc_to_float(r0[x1]);
+    const float bot = hx * rc_to_float(r1[x0]) + lx * rc_to_float(r1[x1]);
+    o[j] = rc_from_float<T>(hy * top + ly * bot);
+  }
+  *reinterpret_cast<typename pw_vec<T, VEC>::type*>(out + n * out_bs + (c * Ho + ho) * (int64_t)Wo + wo0) = o;
 }
 
 template <typename T>
 int launch_resample(int which, const void* x, void* out, int64_t N, int64_t C, int64_t H, int64_t W, int64_t Ho,
                     int64_t Wo, int64_t out_bs, hipStream_t st) {
-  const dim3 grid((unsigned)((Wo + PW_THREADS - 1) / PW_THREADS), (unsigned)(N * C * Ho));
+  constexpr int V = 16 / (int)sizeof(T);
+  const bool vec = Wo % V == 0 && out_bs % V == 0 && aligned16(out);
+  const int64_t total = N * C * Ho * (Wo / (vec ? V : 1));
+  const int64_t nb = (total + PW_THREADS - 1) / PW_THREADS;
+  RC_REQUIRE(nb < (1ll << 31), RC_EINVAL, "too many elements");
+  const dim3 grid((unsigned)nb);
+  const float sy = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, sx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
   if (which == 0) {
-    hipLaunchKernelGGL((pool2x_kernel<T>), grid, dim3(PW_THREADS), 0, st, (const T*)x, (T*)out, (int)H, (int)W, (int)Ho,
-                       (int)Wo, (int)C, out_bs);
+    if (vec)
+      hipLaunchKernelGGL((pool2x_kernel<T, V>), grid, dim3(PW_THREADS), 0, st, (const T*)x, (T*)out, (int)H, (int)W,
+                         (int)Ho, (int)Wo, (int)C, out_bs, total);
+    else
+      hipLaunchKernelGGL((pool2x_kernel<T, 1>), grid, dim3(PW_THREADS), 0, st, (const T*)x, (T*)out, (int)H, (int)W,
+                         (int)Ho, (int)Wo, (int)C, out_bs, total);
     return rc_check_launch("rc_pool2x");
   }
-  const float sy = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, sx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
-  hipLaunchKernelGGL((interp_kernel<T>), grid, dim3(PW_THREADS), 0, st, (const T*)x, (T*)out, (int)H, (int)W, (int)Ho,
-                     (int)Wo, (int)C, out_bs, sy, sx);
+  if (vec)
+    hipLaunchKernelGGL((interp_kernel<T, V>), grid, dim3(PW_THREADS), 0, st, (const T*)x, (T*)out, (int)H, (int)W,
+                       (int)Ho, (int)Wo, (int)C, out_bs, sy, sx, total);
+  else
+    hipLaunchKernelGGL((interp_kernel<T, 1>), grid, dim3(PW_THREADS), 0, st, (const T*)x, (T*)out, (int)H, (int)W,
+                       (int)Ho, (int)Wo, (int)C, out_bs, sy, sx, total);
   return rc_check_launch("rc_interp_bilinear");
 }
 
@@ -996,7 +1032,6 @@ int resample_any(int which, const void* x, void* out, int64_t N, int64_t C, int6
   RC_REQUIRE(x && out, RC_EINVAL, "null pointer argument");
   RC_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && H < (1 << 24) && W < (1 << 24), RC_EINVAL,
              "bad sizes");
-  RC_REQUIRE(N * C * Ho < (1ll << 31), RC_EINVAL, "too many rows");
   RC_REQUIRE(out_bs >= C * Ho * Wo, RC_EINVAL, "output batch stride shorter than one image");
   hipStream_t st = (hipStream_t)stream;
   switch (dtype) {
