@@ -451,6 +451,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch")
     ap.add_argument("--dtype", choices=["f32", "f16", "bf16"], default=None, help="override the feature dtype")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-refine-loop", action="store_true",
+                    help="skip the refinement-loop side metric (torch convolutions, HIP graph capture): for profiler runs")
     ap.add_argument("--adversarial", action="store_true", help="i.i.d. uniform disparity (worst-case gather)")
     args = ap.parse_args()
 
@@ -537,7 +539,7 @@ def main():
         extra.update(fused_convc1(step, cfg, device))      # after the timed region: not part of `value`
     if rank == 0 and cfg["H"] * cfg["W"] * cfg["batch"] <= 300000:
         extra.update(update_ops(cfg, device))              # side metrics, after the timed region
-    if not cfg["train"] and rank == 0 and cfg["H"] * cfg["W"] * cfg["batch"] <= 300000:
+    if not cfg["train"] and rank == 0 and cfg["H"] * cfg["W"] * cfg["batch"] <= 300000 and not args.no_refine_loop:
         extra.update(refine_loop(step, cfg, device))
     if not cfg["train"] and world == 1:       # side metric; kept out of multi-rank runs (no capture beside RCCL)
         extra.update(hip_graph_step(step))

@@ -21,7 +21,7 @@ OURS = ("lookup_convc1_kernel", "convc1_pack_kernel", "adjoint_dense_kernel", "l
         "gru_update_bwd_kernel", "upsample_kernel", "upsample_bwd_kernel", "upsample_bwd_flow_kernel",
         "convc1_bwd_taps_mfma_kernel", "convc1_bwd_weight_mfma_kernel", "convc1_bwd_taps_kernel",
         "convc1_bwd_weight_kernel", "convc1_bwd_reduce_kernel", "seqloss_partial_kernel", "seqloss_final_kernel",
-        "seqloss_bwd_kernel")
+        "seqloss_bwd_kernel", "pool2x_kernel", "interp_kernel", "convc1_pack_bwd_kernel")
 
 
 def short(name):
