@@ -330,7 +330,7 @@ def update_ops(cfg, device, n=50):
                 gru_update_bwd_us=round(t_upd_bwd, 2))
 
 
-def refine_loop(step, cfg, device, reps=3):
+def refine_loop(step, cfg, device, reps=3, capture=True):
     """Everything RAFTStereo.forward does after its encoders (core/raft_stereo.py:100-141) on this package's
     operators, beside the contract's metric: correlation block + default-width update block (hidden 128, 3 GRU
     layers; its dense convolutions are torch's) + convex upsampling, test mode, autocast for 16-bit feature maps.
@@ -369,6 +369,8 @@ def refine_loop(step, cfg, device, reps=3):
                refine_loop_ms_per_iteration=round(dt_s * 1e3 / iters, 3))
     # the same loop captured once in a HIP graph and replayed (nothing in it allocates outside torch's graph
     # pool or synchronises): what a latency-bound caller (the realtime configuration) pays per pair
+    if not capture:       # multi-rank runs: no graph capture beside RCCL
+        return out
     try:
         with torch.no_grad():
             side = torch.cuda.Stream()
@@ -540,7 +542,7 @@ def main():
     if rank == 0 and cfg["H"] * cfg["W"] * cfg["batch"] <= 300000:
         extra.update(update_ops(cfg, device))              # side metrics, after the timed region
     if not cfg["train"] and rank == 0 and cfg["H"] * cfg["W"] * cfg["batch"] <= 300000 and not args.no_refine_loop:
-        extra.update(refine_loop(step, cfg, device))
+        extra.update(refine_loop(step, cfg, device, capture=world == 1))
     if not cfg["train"] and world == 1:       # side metric; kept out of multi-rank runs (no capture beside RCCL)
         extra.update(hip_graph_step(step))
 

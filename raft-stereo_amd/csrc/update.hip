@@ -746,6 +746,7 @@ __device__ __forceinline__ float sl_block_sum(float v, float* red) {
   return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+template <int VEC>
 __global__ __launch_bounds__(PW_THREADS) void seqloss_partial_kernel(sl_ptrs ptrs, int n, int64_t pred_bs,
                                                                      const float* __restrict__ gt,
                                                                      const float* __restrict__ valid, float max_flow,
@@ -758,25 +759,34 @@ __global__ __launch_bounds__(PW_THREADS) void seqloss_partial_kernel(sl_ptrs ptr
 #pragma unroll
   for (int j = 0; j < SL_P; ++j) acc[j] = 0.f;
   const int jlast = n - 1 - i0;  // slot of the last prediction, if this chunk holds it
-  for (int64_t p = (int64_t)blockIdx.x * PW_THREADS + threadIdx.x; p < total; p += (int64_t)nblk * PW_THREADS) {
+  // VEC consecutive pixels per thread and step (whole 16-byte pieces of one image when VEC = 4)
+  typedef typename pw_vec<float, VEC>::type fv;
+  for (int64_t p = ((int64_t)blockIdx.x * PW_THREADS + threadIdx.x) * VEC; p < total;
+       p += (int64_t)nblk * PW_THREADS * VEC) {
     const int64_t b = p / HW, q = p - b * HW;
-    const float g = gt[p], va = valid[p];
-    const bool ok = (va >= 0.5f) && (sqrtf(g * g) < max_flow);
-    cnt += ok ? 1.f : 0.f;
+    const fv g = pw_load<float, VEC>(gt + p), va = pw_load<float, VEC>(valid + p);
+    bool ok[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      ok[e] = (va[e] >= 0.5f) && (sqrtf(g[e] * g[e]) < max_flow);
+      cnt += ok[e] ? 1.f : 0.f;
+    }
 #pragma unroll
     for (int j = 0; j < SL_P; ++j) {
       const int i = min(i0 + j, n - 1);  // past the end: re-read the last one, not accumulated
-      const float x = ptrs.pred[i][b * pred_bs + q];
-      const float d = fabsf(x - g);
+      const fv x = pw_load<float, VEC>(ptrs.pred[i] + b * pred_bs + q);
       if (i0 + j < n) {
-        acc[j] += ok ? d : 0.f;
-        bad += (fabsf(x) <= 3.0e38f) ? 0.f : 1.f;  // false for inf and nan
-        if (j == jlast && ok) {
-          const float e = sqrtf((x - g) * (x - g));
-          epe += e;
-          n1 += e < 1.f ? 1.f : 0.f;
-          n3 += e < 3.f ? 1.f : 0.f;
-          n5 += e < 5.f ? 1.f : 0.f;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          acc[j] += ok[e] ? fabsf(x[e] - g[e]) : 0.f;
+          bad += (fabsf(x[e]) <= 3.0e38f) ? 0.f : 1.f;  // false for inf and nan
+          if (j == jlast && ok[e]) {
+            const float er = sqrtf((x[e] - g[e]) * (x[e] - g[e]));
+            epe += er;
+            n1 += er < 1.f ? 1.f : 0.f;
+            n3 += er < 3.f ? 1.f : 0.f;
+            n5 += er < 5.f ? 1.f : 0.f;
+          }
         }
       }
     }
@@ -836,27 +846,36 @@ __global__ __launch_bounds__(1024) void seqloss_final_kernel(const float* __rest
 }
 
 // d loss / d pred_i = grad_loss * w_i * sign(pred_i - gt) / count on valid' pixels, 0 elsewhere
+template <int VEC>
 __global__ __launch_bounds__(PW_THREADS) void seqloss_bwd_kernel(sl_ptrs ptrs, int n, int64_t pred_bs, int64_t grad_bs,
                                                                  const float* __restrict__ gt,
                                                                  const float* __restrict__ valid, float max_flow,
                                                                  const double* __restrict__ results,
                                                                  const float* __restrict__ grad_loss, int64_t HW,
                                                                  int64_t total) {
-  const int64_t p = (int64_t)blockIdx.x * PW_THREADS + threadIdx.x;
+  typedef typename pw_vec<float, VEC>::type fv;
+  const int64_t p = ((int64_t)blockIdx.x * PW_THREADS + threadIdx.x) * VEC;
   if (p >= total) return;
   const int64_t b = p / HW, q = p - b * HW;
-  const float g = gt[p], va = valid[p];
-  const bool ok = (va >= 0.5f) && (sqrtf(g * g) < max_flow);
+  const fv g = pw_load<float, VEC>(gt + p), va = pw_load<float, VEC>(valid + p);
   const float scale = grad_loss[0] / (float)results[n];
+  float m[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) m[e] = ((va[e] >= 0.5f) && (sqrtf(g[e] * g[e]) < max_flow)) ? scale : 0.f;
   for (int i = 0; i < n; ++i) {  // i is uniform: pointers and weights come through scalar loads
-    const float x = ptrs.pred[i][b * pred_bs + q];
-    const float d = x - g;
-    const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-    ptrs.grad[i][b * grad_bs + q] = ok ? scale * ptrs.weight[i] * sgn : 0.f;
+    const fv x = pw_load<float, VEC>(ptrs.pred[i] + b * pred_bs + q);
+    const float w = ptrs.weight[i];
+    fv o;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float d = x[e] - g[e];
+      o[e] = m[e] * w * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+    }
+    *reinterpret_cast<fv*>(ptrs.grad[i] + b * grad_bs + q) = o;
   }
 }
 
-inline int sl_blocks(int64_t total) {
+inline int sl_blocks(int64_t total) {   // total = work items (pixels or 4-pixel vectors)
   const int64_t nb = (total + PW_THREADS - 1) / PW_THREADS;
   return (int)(nb < SL_MAX_BLOCKS ? nb : SL_MAX_BLOCKS);
 }
@@ -887,10 +906,16 @@ extern "C" int rc_sequence_loss_fwd(const float* const* preds, const float* weig
     ptrs.weight[i] = i < n_predictions ? weights[i] : 0.f;
   }
   const int64_t total = N * HW;
-  const int nblk = sl_blocks(total), nchunks = (n_predictions + SL_P - 1) / SL_P;
+  bool vec = HW % 4 == 0 && pred_batch_stride % 4 == 0 && aligned16(flow_gt) && aligned16(valid);
+  for (int i = 0; i < n_predictions; ++i) vec = vec && aligned16(preds[i]);
+  const int nblk = sl_blocks(vec ? total / 4 : total), nchunks = (n_predictions + SL_P - 1) / SL_P;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(seqloss_partial_kernel, dim3(nblk, nchunks), dim3(PW_THREADS), 0, st, ptrs, n_predictions,
-                     pred_batch_stride, flow_gt, valid, max_flow, (float*)work, HW, total);
+  if (vec)
+    hipLaunchKernelGGL(seqloss_partial_kernel<4>, dim3(nblk, nchunks), dim3(PW_THREADS), 0, st, ptrs, n_predictions,
+                       pred_batch_stride, flow_gt, valid, max_flow, (float*)work, HW, total);
+  else
+    hipLaunchKernelGGL(seqloss_partial_kernel<1>, dim3(nblk, nchunks), dim3(PW_THREADS), 0, st, ptrs, n_predictions,
+                       pred_batch_stride, flow_gt, valid, max_flow, (float*)work, HW, total);
   int rc = rc_check_launch("rc_sequence_loss_fwd");
   if (rc) return rc;
   hipLaunchKernelGGL(seqloss_final_kernel, dim3(1), dim3(1024), 0, st, (const float*)work, nblk, n_predictions,
@@ -917,11 +942,20 @@ extern "C" int rc_sequence_loss_bwd(const float* const* preds, float* const* gra
     ptrs.weight[i] = i < n_predictions ? weights[i] : 0.f;
   }
   const int64_t total = N * HW;
-  const int64_t nb = (total + PW_THREADS - 1) / PW_THREADS;
+  bool vec = HW % 4 == 0 && pred_batch_stride % 4 == 0 && grad_batch_stride % 4 == 0 && aligned16(flow_gt) &&
+             aligned16(valid);
+  for (int i = 0; i < n_predictions; ++i) vec = vec && aligned16(preds[i]) && aligned16(grad_preds[i]);
+  const int64_t items = vec ? total / 4 : total;
+  const int64_t nb = (items + PW_THREADS - 1) / PW_THREADS;
   RC_REQUIRE(nb < (1ll << 31), RC_EINVAL, "too many pixels");
-  hipLaunchKernelGGL(seqloss_bwd_kernel, dim3((unsigned)nb), dim3(PW_THREADS), 0, (hipStream_t)stream, ptrs,
-                     n_predictions, pred_batch_stride, grad_batch_stride, flow_gt, valid, max_flow, results, grad_loss,
-                     HW, total);
+  if (vec)
+    hipLaunchKernelGGL(seqloss_bwd_kernel<4>, dim3((unsigned)nb), dim3(PW_THREADS), 0, (hipStream_t)stream, ptrs,
+                       n_predictions, pred_batch_stride, grad_batch_stride, flow_gt, valid, max_flow, results,
+                       grad_loss, HW, total);
+  else
+    hipLaunchKernelGGL(seqloss_bwd_kernel<1>, dim3((unsigned)nb), dim3(PW_THREADS), 0, (hipStream_t)stream, ptrs,
+                       n_predictions, pred_batch_stride, grad_batch_stride, flow_gt, valid, max_flow, results,
+                       grad_loss, HW, total);
   return rc_check_launch("rc_sequence_loss_bwd");
 }
 
