@@ -330,6 +330,68 @@ def update_ops(cfg, device, n=50):
                 gru_update_bwd_us=round(t_upd_bwd, 2))
 
 
+def _torch_ops_refine(blk, corr_fn, net_list, inp_list, args, iters):
+    """The same loop spelled with torch ops on the same parameters, the way the reference's update block and
+    forward pass are written (core/update.py:23-32, 77-85, 115-138; core/raft_stereo.py:55-67, 108-139): plain
+    lookups from the same correlation block, then torch for everything else.  Baseline for `refine_loop` only."""
+    import torch.nn.functional as F
+    amp = args.mixed_precision
+    layers = args.n_gru_layers
+    f = 2 ** args.n_downsample
+
+    def gru(m, h, cz, cr, cq, *xs):
+        x = torch.cat(xs, dim=1)
+        hx = torch.cat([h, x], dim=1)
+        z = torch.sigmoid(m.convz(hx) + cz)
+        r = torch.sigmoid(m.convr(hx) + cr)
+        q = torch.tanh(m.convq(torch.cat([r * h, x], dim=1)) + cq)
+        return (1 - z) * h + z * q
+
+    def pool2x(x):
+        return F.avg_pool2d(x, 3, stride=2, padding=1)
+
+    def interp(x, dest):
+        return F.interpolate(x, dest.shape[2:], mode="bilinear", align_corners=True)
+
+    def block(net, corr=None, flow=None, iter08=True, iter16=True, iter32=True, update=True):
+        if iter32:
+            net[2] = gru(blk.gru32, net[2], *inp_list[2], pool2x(net[1]))
+        if iter16:
+            net[1] = gru(blk.gru16, net[1], *inp_list[1], pool2x(net[0]), *([interp(net[2], net[1])] if layers > 2 else []))
+        if iter08:
+            e = blk.encoder
+            cor = F.relu(e.convc2(F.relu(e.convc1(corr))))
+            flo = F.relu(e.convf2(F.relu(e.convf1(flow))))
+            motion = torch.cat([F.relu(e.conv(torch.cat([cor, flo], dim=1))), flow], dim=1)
+            net[0] = gru(blk.gru08, net[0], *inp_list[0], motion, *([interp(net[1], net[0])] if layers > 1 else []))
+        if not update:
+            return net
+        return net, .25 * blk.mask(net[0]), blk.flow_head(net[0])
+
+    n, _, h, w = net_list[0].shape
+    ys, xs = torch.meshgrid(torch.arange(h, device=net_list[0].device), torch.arange(w, device=net_list[0].device),
+                            indexing="ij")
+    coords0 = torch.stack([xs, ys], dim=0).float()[None].repeat(n, 1, 1, 1)
+    coords1 = coords0.clone()
+    net = list(net_list)
+    for itr in range(iters):
+        corr = corr_fn(coords1)
+        flow = coords1 - coords0
+        with torch.autocast("cuda", enabled=amp):
+            if layers == 3 and args.slow_fast_gru:
+                net = block(net, iter32=True, iter16=False, iter08=False, update=False)
+            if layers >= 2 and args.slow_fast_gru:
+                net = block(net, iter32=layers == 3, iter16=True, iter08=False, update=False)
+            net, up_mask, delta_flow = block(net, corr, flow, iter32=layers == 3, iter16=layers >= 2)
+        delta_flow[:, 1] = 0.0
+        coords1 = coords1 + delta_flow
+    fl = coords1 - coords0
+    mask = torch.softmax(up_mask.view(n, 1, 9, f, f, h, w), dim=2)
+    up = F.unfold(f * fl, [3, 3], padding=1).view(n, 2, 9, 1, 1, h, w)
+    up = torch.sum(mask * up, dim=2).permute(0, 1, 4, 2, 5, 3).reshape(n, 2, f * h, f * w)
+    return fl, up[:, :1]
+
+
 def refine_loop(step, cfg, device, reps=3, capture=True):
     """Everything RAFTStereo.forward does after its encoders (core/raft_stereo.py:100-141) on this package's
     operators, beside the contract's metric: correlation block + default-width update block (hidden 128, 3 GRU
@@ -363,7 +425,22 @@ def refine_loop(step, cfg, device, reps=3, capture=True):
             once()
         torch.cuda.synchronize()
         dt_s = (time.perf_counter() - t0) / reps
-    out = dict(refine_loop_config=f"{args.n_gru_layers} GRU layers, slow_fast_gru={args.slow_fast_gru}, hidden 128, "
+    def once_torch():
+        corr_fn = step.cls(step.f1, step.f2, num_levels=LEVELS, radius=RADIUS)
+        return _torch_ops_refine(blk, corr_fn, net, inp, args, iters)
+
+    with torch.no_grad():
+        ref_up = once_torch()[1]
+        agree = float((once()[1] - ref_up).abs().mean())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            once_torch()
+        torch.cuda.synchronize()
+        dt_torch = (time.perf_counter() - t0) / reps
+    out = dict(refine_loop_torch_ops_ms=round(dt_torch * 1e3, 2),
+               refine_loop_mean_abs_diff_px_vs_torch_ops=round(agree, 5))
+    out.update(refine_loop_config=f"{args.n_gru_layers} GRU layers, slow_fast_gru={args.slow_fast_gru}, hidden 128, "
                                   f"{iters} iterations, 1/{2 ** nd} resolution, autocast={amp}",
                refine_loop_ms=round(dt_s * 1e3, 2), refine_loop_pairs_per_s=round(B / dt_s, 2),
                refine_loop_ms_per_iteration=round(dt_s * 1e3 / iters, 3))
