@@ -1,7 +1,7 @@
 /*
  * raftcorr.h -- C-ABI of libraftcorr_hip.so: the MI355X (gfx950) correlation hot path of
  * RAFT-Stereo (volume build + pooled pyramid, per-iteration lookup fwd/bwd, build adjoint,
- * on-the-fly "alt" lookup).
+ * on-the-fly "alt" lookup) and the pointwise work of a GRU iteration around it.
  *
  * Conventions
  *   - every pointer is a DEVICE pointer owned by the caller; the library never allocates,
@@ -28,6 +28,13 @@
  *                      caller's own row-major [B,H,W1,W2] single-level volume
  *   rc_alt_prepare,
  *   rc_alt_fwd         core/corr.py:64-107 PytorchAlternateCorrBlock1D (volume never built)
+ * and, on either side of the lookup (SURVEY.md section 8 f):
+ *   rc_lookup_convc1_fwd, rc_convc1_bwd     core/update.py:71,78 on core/raft_stereo.py:110
+ *   rc_lookup_fwd_update                    core/raft_stereo.py:109-111,120-123
+ *   rc_gru_gate_r, rc_gru_update (+ _bwd)   core/update.py:23-32
+ *   rc_pool2x, rc_interp_bilinear           core/update.py:87-95
+ *   rc_upsample_flow_fwd/bwd                core/raft_stereo.py:55-67
+ *   rc_sequence_loss_fwd/bwd                train_stereo.py:35-70
  */
 #ifndef RAFTCORR_H
 #define RAFTCORR_H
