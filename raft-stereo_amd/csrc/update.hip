@@ -1033,32 +1033,37 @@ __global__ __launch_bounds__(PW_THREADS) void interp_kernel(const T* __restrict_
   *reinterpret_cast<typename pw_vec<T, VEC>::type*>(out + n * out_bs + (c * Ho + ho) * (int64_t)Wo + wo0) = o;
 }
 
+template <typename T, int V>
+int launch_resample_v(int which, const void* x, void* out, int64_t N, int64_t C, int64_t H, int64_t W, int64_t Ho,
+                      int64_t Wo, int64_t out_bs, hipStream_t st) {
+  const int64_t total = N * C * Ho * (Wo / V);
+  const int64_t nb = (total + PW_THREADS - 1) / PW_THREADS;
+  RC_REQUIRE(nb < (1ll << 31), RC_EINVAL, "too many elements");
+  const dim3 grid((unsigned)nb);
+  if (which == 0) {
+    hipLaunchKernelGGL((pool2x_kernel<T, V>), grid, dim3(PW_THREADS), 0, st, (const T*)x, (T*)out, (int)H, (int)W,
+                       (int)Ho, (int)Wo, (int)C, out_bs, total);
+    return rc_check_launch("rc_pool2x");
+  }
+  const float sy = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, sx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+  hipLaunchKernelGGL((interp_kernel<T, V>), grid, dim3(PW_THREADS), 0, st, (const T*)x, (T*)out, (int)H, (int)W,
+                     (int)Ho, (int)Wo, (int)C, out_bs, sy, sx, total);
+  return rc_check_launch("rc_interp_bilinear");
+}
+
+// the widest store (16, 8 or 4 bytes of consecutive outputs) that output rows and the output pointer allow
 template <typename T>
 int launch_resample(int which, const void* x, void* out, int64_t N, int64_t C, int64_t H, int64_t W, int64_t Ho,
                     int64_t Wo, int64_t out_bs, hipStream_t st) {
   constexpr int V = 16 / (int)sizeof(T);
-  const bool vec = Wo % V == 0 && out_bs % V == 0 && aligned16(out);
-  const int64_t total = N * C * Ho * (Wo / (vec ? V : 1));
-  const int64_t nb = (total + PW_THREADS - 1) / PW_THREADS;
-  RC_REQUIRE(nb < (1ll << 31), RC_EINVAL, "too many elements");
-  const dim3 grid((unsigned)nb);
-  const float sy = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, sx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
-  if (which == 0) {
-    if (vec)
-      hipLaunchKernelGGL((pool2x_kernel<T, V>), grid, dim3(PW_THREADS), 0, st, (const T*)x, (T*)out, (int)H, (int)W,
-                         (int)Ho, (int)Wo, (int)C, out_bs, total);
-    else
-      hipLaunchKernelGGL((pool2x_kernel<T, 1>), grid, dim3(PW_THREADS), 0, st, (const T*)x, (T*)out, (int)H, (int)W,
-                         (int)Ho, (int)Wo, (int)C, out_bs, total);
-    return rc_check_launch("rc_pool2x");
+  const uintptr_t addr = (uintptr_t)out;
+  auto fits = [&](int v) { return Wo % v == 0 && out_bs % v == 0 && addr % (v * sizeof(T)) == 0; };
+  if (fits(V)) return launch_resample_v<T, V>(which, x, out, N, C, H, W, Ho, Wo, out_bs, st);
+  if (fits(V / 2)) return launch_resample_v<T, V / 2>(which, x, out, N, C, H, W, Ho, Wo, out_bs, st);
+  if constexpr (V >= 8) {
+    if (fits(V / 4)) return launch_resample_v<T, V / 4>(which, x, out, N, C, H, W, Ho, Wo, out_bs, st);
   }
-  if (vec)
-    hipLaunchKernelGGL((interp_kernel<T, V>), grid, dim3(PW_THREADS), 0, st, (const T*)x, (T*)out, (int)H, (int)W,
-                       (int)Ho, (int)Wo, (int)C, out_bs, sy, sx, total);
-  else
-    hipLaunchKernelGGL((interp_kernel<T, 1>), grid, dim3(PW_THREADS), 0, st, (const T*)x, (T*)out, (int)H, (int)W,
-                       (int)Ho, (int)Wo, (int)C, out_bs, sy, sx, total);
-  return rc_check_launch("rc_interp_bilinear");
+  return launch_resample_v<T, 1>(which, x, out, N, C, H, W, Ho, Wo, out_bs, st);
 }
 
 int resample_any(int which, const void* x, void* out, int64_t N, int64_t C, int64_t H, int64_t W, int64_t Ho,
