@@ -970,7 +970,8 @@ namespace {
 // vectors, else 1): a flat index over all output vectors keeps every block full whatever the row length.
 template <typename T, int VEC>
 __global__ __launch_bounds__(PW_THREADS) void pool2x_kernel(const T* __restrict__ x, T* __restrict__ out, int H, int W,
-                                                            int Ho, int Wo, int C, int64_t out_bs, int64_t total) {
+                                                            int Ho, int Wo, int C, int64_t out_bs, int64_t total,
+                                                            int vec_in) {
   const int64_t v = (int64_t)blockIdx.x * PW_THREADS + threadIdx.x;
   if (v >= total) return;
   const int wv = Wo / VEC;
@@ -989,10 +990,17 @@ __global__ __launch_bounds__(PW_THREADS) void pool2x_kernel(const T* __restrict_
     const T* row = src + (int64_t)h * W;
     // the 2 VEC + 1 inputs under this thread's outputs: columns 2 wo0 - 1 .. 2 wo0 + 2 VEC - 1
     float in[2 * VEC + 1];
+    if (vec_in) {  // launch-uniform: input rows are whole, aligned vectors of 2 VEC elements
+      const auto vr = pw_load<T, 2 * VEC>(row + 2 * wo0);
+      in[0] = wo0 > 0 ? rc_to_float(row[2 * wo0 - 1]) : 0.f;
 #pragma unroll
-    for (int q = 0; q < 2 * VEC + 1; ++q) {
-      const int w = 2 * wo0 - 1 + q;
-      in[q] = (unsigned)w < (unsigned)W ? rc_to_float(row[w]) : 0.f;
+      for (int q = 0; q < 2 * VEC; ++q) in[q + 1] = rc_to_float(vr[q]);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 2 * VEC + 1; ++q) {
+        const int w = 2 * wo0 - 1 + q;
+        in[q] = (unsigned)w < (unsigned)W ? rc_to_float(row[w]) : 0.f;
+      }
     }
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc[j] += (in[2 * j] + in[2 * j + 1]) + in[2 * j + 2];
@@ -1041,8 +1049,9 @@ int launch_resample_v(int which, const void* x, void* out, int64_t N, int64_t C,
   RC_REQUIRE(nb < (1ll << 31), RC_EINVAL, "too many elements");
   const dim3 grid((unsigned)nb);
   if (which == 0) {
+    const int vec_in = W % (2 * V) == 0 && (uintptr_t)x % (2 * V * sizeof(T)) == 0;
     hipLaunchKernelGGL((pool2x_kernel<T, V>), grid, dim3(PW_THREADS), 0, st, (const T*)x, (T*)out, (int)H, (int)W,
-                       (int)Ho, (int)Wo, (int)C, out_bs, total);
+                       (int)Ho, (int)Wo, (int)C, out_bs, total, vec_in);
     return rc_check_launch("rc_pool2x");
   }
   const float sy = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, sx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
