@@ -29,8 +29,37 @@ from core.corr import CorrBlock1D  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
+def two_layer_case():
+    """The realtime configuration's block (n_gru_layers=2, n_downsample=3): one mid-resolution partial call
+    (core/raft_stereo.py:115-116) and one full call.  Forward only."""
+    torch.manual_seed(78)
+    hid, H, W = 16, 10, 14
+    args = Namespace(corr_levels=4, corr_radius=4, n_gru_layers=2, n_downsample=3)
+    blk = BasicMultiUpdateBlock(args, hidden_dims=[hid] * 3)
+    with torch.no_grad():
+        for p in blk.parameters():
+            p.mul_(3.0)
+        sizes = [(H, W), (H // 2, W // 2)]
+        net = [torch.tanh(torch.randn(1, hid, h, w)) for h, w in sizes] + [torch.zeros(1, hid, 1, 1)]
+        ctx = [torch.randn(1, 3 * hid, h, w) for h, w in sizes]
+        inp = [list(c.split(split_size=hid, dim=1)) for c in ctx] + [None]
+        corr, flow = torch.randn(1, 36, H, W), torch.randn(1, 2, H, W)
+        rec = {"corr": corr, "flow": flow, "net0": net[0], "net1": net[1], "ctx0": ctx[0], "ctx1": ctx[1]}
+        part = blk([n.clone() for n in net], inp, iter32=False, iter16=True, iter08=False, update=False)
+        rec["partial_net1"] = part[1]
+        out_net, mask, delta = blk([n.clone() for n in net], inp, corr, flow, iter32=False, iter16=True)
+        rec.update(out_net0=out_net[0], out_net1=out_net[1], mask=mask, delta_flow=delta)
+        for k, v in blk.state_dict().items():
+            rec["w_" + k] = v
+    rec = {k: v.detach().numpy().copy() for k, v in rec.items()}
+    path = os.path.join(HERE, "block_l2_h16.npz")
+    np.savez_compressed(path, **rec)
+    print("l2", {k: v.shape for k, v in rec.items() if not k.startswith("w_")}, os.path.getsize(path) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
+    two_layer_case()
     torch.manual_seed(77)
     hid, H, W, D = 16, 16, 24, 32
     args = Namespace(corr_levels=4, corr_radius=4, n_gru_layers=3, n_downsample=2)

@@ -86,3 +86,26 @@ def test_backward_matches_reference_autograd(setup, fused):
     for k in g:
         if k.startswith("dw_"):
             assert rel(params[k[3:]].grad, g[k]) < 1e-3, k
+
+
+def test_two_layer_realtime_block_matches_reference(golden):
+    """n_gru_layers=2, n_downsample=3 (the realtime configuration): partial mid-resolution call and full call."""
+    import raft_stereo_amd as R
+    g = golden("block_l2_h16")
+    args = Namespace(corr_levels=4, corr_radius=4, n_gru_layers=2, n_downsample=3)
+    blk = R.BasicMultiUpdateBlockHip(args, hidden_dims=[16] * 3).cuda()
+    blk.load_state_dict({k[2:]: dev(v) for k, v in g.items() if k.startswith("w_")}, strict=True)
+
+    def fresh():
+        net = [dev(g["net0"]), dev(g["net1"]), torch.zeros(1, 16, 1, 1, device="cuda")]
+        inp = [list(dev(g[f"ctx{i}"]).split(split_size=16, dim=1)) for i in range(2)] + [None]
+        return net, inp
+    with torch.no_grad():
+        net, inp = fresh()
+        part = blk(net, inp, iter32=False, iter16=True, iter08=False, update=False)
+        assert rel(part[1], g["partial_net1"]) < 1e-4
+        net, inp = fresh()
+        out_net, mask, delta = blk(net, inp, dev(g["corr"]), dev(g["flow"]), iter32=False, iter16=True)
+    assert rel(out_net[0], g["out_net0"]) < 1e-4 and rel(out_net[1], g["out_net1"]) < 1e-4
+    assert tuple(mask.shape) == g["mask"].shape and rel(mask, g["mask"]) < 1e-4
+    assert rel(delta, g["delta_flow"]) < 1e-4
