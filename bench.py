@@ -330,7 +330,7 @@ def update_ops(cfg, device, n=50):
                 gru_update_bwd_us=round(t_upd_bwd, 2))
 
 
-def _torch_ops_refine(blk, corr_fn, net_list, inp_list, args, iters):
+def _torch_ops_refine(blk, corr_fn, net_list, inp_list, args, iters, test_mode=True):
     """The same loop spelled with torch ops on the same parameters, the way the reference's update block and
     forward pass are written (core/update.py:23-32, 77-85, 115-138; core/raft_stereo.py:55-67, 108-139): plain
     lookups from the same correlation block, then torch for everything else.  Baseline for `refine_loop` only."""
@@ -373,8 +373,9 @@ def _torch_ops_refine(blk, corr_fn, net_list, inp_list, args, iters):
                             indexing="ij")
     coords0 = torch.stack([xs, ys], dim=0).float()[None].repeat(n, 1, 1, 1)
     coords1 = coords0.clone()
-    net = list(net_list)
+    net, preds = list(net_list), []
     for itr in range(iters):
+        coords1 = coords1.detach()
         corr = corr_fn(coords1)
         flow = coords1 - coords0
         with torch.autocast("cuda", enabled=amp):
@@ -385,11 +386,14 @@ def _torch_ops_refine(blk, corr_fn, net_list, inp_list, args, iters):
             net, up_mask, delta_flow = block(net, corr, flow, iter32=layers == 3, iter16=layers >= 2)
         delta_flow[:, 1] = 0.0
         coords1 = coords1 + delta_flow
-    fl = coords1 - coords0
-    mask = torch.softmax(up_mask.view(n, 1, 9, f, f, h, w), dim=2)
-    up = F.unfold(f * fl, [3, 3], padding=1).view(n, 2, 9, 1, 1, h, w)
-    up = torch.sum(mask * up, dim=2).permute(0, 1, 4, 2, 5, 3).reshape(n, 2, f * h, f * w)
-    return fl, up[:, :1]
+        if test_mode and itr < iters - 1:
+            continue
+        fl = coords1 - coords0
+        mask = torch.softmax(up_mask.view(n, 1, 9, f, f, h, w), dim=2)
+        up = F.unfold(f * fl, [3, 3], padding=1).view(n, 2, 9, 1, 1, h, w)
+        up = torch.sum(mask * up, dim=2).permute(0, 1, 4, 2, 5, 3).reshape(n, 2, f * h, f * w)
+        preds.append(up[:, :1])
+    return (fl, preds[-1]) if test_mode else preds
 
 
 def refine_loop(step, cfg, device, reps=3, capture=True):
@@ -469,6 +473,70 @@ def refine_loop(step, cfg, device, reps=3, capture=True):
         out["refine_loop_hip_graph_ms"] = None
         out["refine_loop_hip_graph_error"] = str(e)[:120]
     return out
+
+
+def refine_train_step(step, cfg, device, reps=2):
+    """A training step of everything after the encoders (SceneFlow shape): refinement loop in training mode
+    (a prediction per iteration), sequence loss, backward down to the feature maps and the update block's
+    parameters -- this package's operators against the same step in torch ops (reference-style loss included).
+    Wall clock, synchronised; random-init weights, synthetic context tensors and ground truth."""
+    from argparse import Namespace
+    import raft_stereo_amd as R
+    B, H, W = cfg["batch"], cfg["H"], cfg["W"]
+    dt = DTYPES[cfg["dtype"]]
+    amp = dt != torch.float32
+    args = Namespace(hidden_dims=[128] * 3, corr_levels=LEVELS, corr_radius=RADIUS, n_downsample=2,
+                     slow_fast_gru=False, n_gru_layers=3, mixed_precision=amp)
+    g = torch.Generator(device=device).manual_seed(6)
+    blk = R.BasicMultiUpdateBlockHip(args, hidden_dims=args.hidden_dims).to(device)
+    sizes = [(H, W), ((H + 1) // 2, (W + 1) // 2), ((H + 3) // 4, (W + 3) // 4)]
+    net = [torch.tanh(torch.randn((B, 128, h, w), generator=g, device=device)).to(dt) for h, w in sizes]
+    inp = [list(torch.randn((B, 384, h, w), generator=g, device=device).to(dt).split(128, dim=1)) for h, w in sizes]
+    gt = -torch.rand((B, 1, 4 * H, 4 * W), generator=g, device=device) * 50
+    valid = (torch.rand((B, 4 * H, 4 * W), generator=g, device=device) > 0.1).float()
+    iters = cfg["iters"]
+
+    def ours():
+        blk.zero_grad(set_to_none=True)
+        step.f1.grad = step.f2.grad = None
+        corr_fn = step.cls(step.f1, step.f2, num_levels=LEVELS, radius=RADIUS)
+        preds = R.refine_disparity(blk, corr_fn, net, inp, args, iters=iters, test_mode=False)
+        loss, _ = R.sequence_loss_hip(preds, gt, valid)
+        loss.backward()
+        return loss
+
+    def torch_ops():
+        blk.zero_grad(set_to_none=True)
+        step.f1.grad = step.f2.grad = None
+        corr_fn = step.cls(step.f1, step.f2, num_levels=LEVELS, radius=RADIUS)
+        preds = _torch_ops_refine(blk, corr_fn, net, inp, args, iters, test_mode=False)
+        vm = ((valid >= 0.5) & (torch.sum(gt ** 2, dim=1).sqrt() < 700)).unsqueeze(1)
+        loss = 0.0
+        for i, p in enumerate(preds):
+            loss = loss + 0.9 ** (15 / (iters - 1) * (iters - i - 1)) * (p - gt).abs()[vm.bool()].mean()
+        epe = torch.sum((preds[-1] - gt) ** 2, dim=1).sqrt().view(-1)[vm.view(-1)]
+        _ = (epe.mean().item(), (epe < 1).float().mean().item())
+        loss.backward()
+        return loss
+
+    def wall(fn):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            last = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3, float(last)
+
+    torch.cuda.reset_peak_memory_stats(device)
+    t_ours, l_ours = wall(ours)
+    peak_ours = torch.cuda.max_memory_allocated(device) / 2 ** 30
+    torch.cuda.reset_peak_memory_stats(device)
+    t_torch, l_torch = wall(torch_ops)
+    peak_torch = torch.cuda.max_memory_allocated(device) / 2 ** 30
+    return dict(refine_train_step_ms=round(t_ours, 1), refine_train_step_torch_ops_ms=round(t_torch, 1),
+                refine_train_loss=round(l_ours, 4), refine_train_loss_torch_ops=round(l_torch, 4),
+                refine_train_peak_gib=round(peak_ours, 2), refine_train_peak_gib_torch_ops=round(peak_torch, 2))
 
 
 def hip_graph_step(step, n=50):
@@ -620,6 +688,8 @@ def main():
         extra.update(update_ops(cfg, device))              # side metrics, after the timed region
     if not cfg["train"] and rank == 0 and cfg["H"] * cfg["W"] * cfg["batch"] <= 300000 and not args.no_refine_loop:
         extra.update(refine_loop(step, cfg, device, capture=world == 1))
+    if cfg["train"] and rank == 0 and not args.no_refine_loop:
+        extra.update(refine_train_step(step, cfg, device))
     if not cfg["train"] and world == 1:       # side metric; kept out of multi-rank runs (no capture beside RCCL)
         extra.update(hip_graph_step(step))
 

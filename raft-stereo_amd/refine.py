@@ -6,7 +6,7 @@ its encoders (core/raft_stereo.py:100-141 of the reference), on this package's o
 `corr_fn` is a correlation block (`make_corr_fn(...)`), `update_block` a BasicMultiUpdateBlockHip (or the
 reference's own block), `net_list` / `inp_list` the context encoder's hidden states and per-scale context
 triples (core/raft_stereo.py:84-88).  Returns what the reference returns: the list of upsampled disparity
-predictions, or `(coords1 - coords0, flow_up)` in test mode.  In test mode with a reg_hip block and a
+predictions, or `(coords1 - coords0, flow_up)` in test mode.  With a reg_hip block and a
 BasicMultiUpdateBlockHip the lookup is fused with the motion encoder's first layer.
 """
 import torch
@@ -28,7 +28,9 @@ def refine_disparity(update_block, corr_fn, net_list, inp_list, args, iters=12, 
     amp = bool(getattr(args, "mixed_precision", False))
     coords0 = pixel_grid(n, h, w, device)
     coords1 = coords0.clone() if flow_init is None else coords0 + flow_init
-    fuse = test_mode and isinstance(update_block, BasicMultiUpdateBlockHip) and hasattr(corr_fn, "lookup_convc1") \
+    # reg_hip + this package's update block: the lookup is fused with the motion encoder's first layer, in test
+    # mode and in training (the backward recomputes the lookup instead of keeping 36 channels per iteration)
+    fuse = isinstance(update_block, BasicMultiUpdateBlockHip) and hasattr(corr_fn, "lookup_convc1") \
         and corr_fn.radius <= 7
     net_list = list(net_list)
     predictions, flow_up = [], None
