@@ -290,12 +290,18 @@ int rc_gru_gate_r_bwd(const void* convr_out, const void* cr, int64_t cr_batch_st
  * avg_pool2d(x, 3, stride=2, padding=1) -> [N, C, (H-1)/2+1, (W-1)/2+1] (padding counted: always / 9), and
  * interp(x, dest) = bilinear resize to Ho x Wo with align_corners=True.  x: [N,C,H,W] contiguous of `dtype`;
  * out: images out_batch_stride elements apart (a channel slice of the GRU's input buffer works); fp32
- * arithmetic, result rounded to `dtype`.  Forward only (the update block keeps torch's ops when it trains).
+ * arithmetic, result rounded to `dtype`.
  */
 int rc_pool2x(const void* x, void* out, int64_t N, int64_t C, int64_t H, int64_t W,
               int64_t out_batch_stride, int dtype, void* stream);
 int rc_interp_bilinear(const void* x, void* out, int64_t N, int64_t C, int64_t H, int64_t W,
                        int64_t Ho, int64_t Wo, int64_t out_batch_stride, int dtype, void* stream);
+/* Their adjoints (gathers, no atomics): grad_out is the contiguous gradient of the forward's output
+ * ([N,C,Ho,Wo], Ho/Wo of pool2x as above), grad_x [N,C,H,W] is overwritten; both of `dtype`. */
+int rc_pool2x_bwd(const void* grad_out, void* grad_x, int64_t N, int64_t C, int64_t H, int64_t W,
+                  int dtype, void* stream);
+int rc_interp_bilinear_bwd(const void* grad_out, void* grad_x, int64_t N, int64_t C, int64_t H,
+                           int64_t W, int64_t Ho, int64_t Wo, int dtype, void* stream);
 
 /*
  * SURVEY.md section 8(f) rank 4 -- convex upsampling, RAFTStereo.upsample_flow (core/raft_stereo.py:55-67):

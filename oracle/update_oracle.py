@@ -181,6 +181,35 @@ def interp(x, Ho, Wo):
     return (top * (1 - ly) + bot * ly).astype(F32)
 
 
+def pool2x_bwd(grad_out, H, W):
+    """Adjoint of pool2x for an [N,C,H,W] input."""
+    g = np.asarray(grad_out, dtype=np.float64)
+    N, C, Ho, Wo = g.shape
+    dpad = np.zeros((N, C, 2 * Ho + 1, 2 * Wo + 1))
+    for dy in range(3):
+        for dx in range(3):
+            dpad[:, :, dy:dy + 2 * Ho:2, dx:dx + 2 * Wo:2] += g / 9.0
+    return dpad[:, :, 1:H + 1, 1:W + 1].astype(F32)
+
+
+def interp_bwd(grad_out, H, W):
+    """Adjoint of interp for an [N,C,H,W] input (same fp32 source positions as the forward)."""
+    g = np.asarray(grad_out, dtype=np.float64)
+    N, C, Ho, Wo = g.shape
+
+    def axis(n_in, n_out):
+        s = F32(n_in - 1) / F32(n_out - 1) if n_out > 1 else F32(0)
+        f = (s * np.arange(n_out, dtype=F32)).astype(F32)
+        i0 = np.minimum(f.astype(int), n_in - 1)
+        i1 = np.minimum(i0 + 1, n_in - 1)
+        l = (f - i0.astype(F32)).astype(np.float64)
+        m = np.zeros((n_out, n_in))
+        np.add.at(m, (np.arange(n_out), i0), 1 - l)
+        np.add.at(m, (np.arange(n_out), i1), l)
+        return m
+    return np.einsum("ncop,oy,px->ncyx", g, axis(H, Ho), axis(W, Wo)).astype(F32)
+
+
 def rel_to_max(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))

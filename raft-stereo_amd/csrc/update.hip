@@ -1102,3 +1102,111 @@ extern "C" int rc_interp_bilinear(const void* x, void* out, int64_t N, int64_t C
                                   int64_t Wo, int64_t out_batch_stride, int dtype, void* stream) {
   return resample_any(1, x, out, N, C, H, W, Ho, Wo, out_batch_stride, dtype, stream);
 }
+
+// ---- adjoints of the between-scale glue (training): gathers, no atomics.  One thread per INPUT element.
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(PW_THREADS) void pool2x_bwd_kernel(const T* __restrict__ g, T* __restrict__ dx, int H, int W,
+                                                                int Ho, int Wo, int64_t total) {
+  const int64_t idx = (int64_t)blockIdx.x * PW_THREADS + threadIdx.x;
+  if (idx >= total) return;
+  const int w = (int)(idx % W);
+  const int64_t r = idx / W;
+  const int h = (int)(r % H);
+  const int64_t nc = r / H;
+  const T* src = g + nc * (int64_t)Ho * Wo;
+  // outputs whose 3x3 window (centre 2 ho, 2 wo) covers (h, w): |2 ho - h| <= 1
+  const int ho0 = h >> 1, ho1 = (h & 1) ? ho0 + 1 : ho0;
+  const int wo0 = w >> 1, wo1 = (w & 1) ? wo0 + 1 : wo0;
+  float acc = 0.f;
+  for (int ho = ho0; ho <= ho1; ++ho) {
+    if (ho >= Ho) continue;
+    for (int wo = wo0; wo <= wo1; ++wo)
+      if (wo < Wo) acc += rc_to_float(src[(int64_t)ho * Wo + wo]);
+  }
+  dx[idx] = rc_from_float<T>(acc * (1.0f / 9.0f));
+}
+
+// weight of input index `i` in output index `o` along one axis (the forward's own fp32 arithmetic)
+__device__ __forceinline__ float interp_axis_weight(int o, int i, float scale, int n_in) {
+  const float f = scale * (float)o;
+  const int i0 = min((int)f, n_in - 1), i1 = min(i0 + 1, n_in - 1);
+  const float l = f - (float)i0;
+  return (i0 == i ? 1.0f - l : 0.f) + (i1 == i ? l : 0.f);
+}
+
+template <typename T>
+__global__ __launch_bounds__(PW_THREADS) void interp_bwd_kernel(const T* __restrict__ g, T* __restrict__ dx, int H, int W,
+                                                                int Ho, int Wo, float sy, float sx, float isy, float isx,
+                                                                int64_t total) {
+  const int64_t idx = (int64_t)blockIdx.x * PW_THREADS + threadIdx.x;
+  if (idx >= total) return;
+  const int x = (int)(idx % W);
+  const int64_t r = idx / W;
+  const int y = (int)(r % H);
+  const int64_t nc = r / H;
+  const T* src = g + nc * (int64_t)Ho * Wo;
+  // outputs that can touch input row y: source position in (y - 1, y + 1); one index of slack on both sides,
+  // the exact weight decides
+  const int ho_lo = sy > 0.f ? max(0, (int)floorf(((float)y - 1.0f) * isy) - 1) : 0;
+  const int ho_hi = sy > 0.f ? min(Ho - 1, (int)ceilf(((float)y + 1.0f) * isy) + 1) : Ho - 1;
+  const int wo_lo = sx > 0.f ? max(0, (int)floorf(((float)x - 1.0f) * isx) - 1) : 0;
+  const int wo_hi = sx > 0.f ? min(Wo - 1, (int)ceilf(((float)x + 1.0f) * isx) + 1) : Wo - 1;
+  float acc = 0.f;
+  for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+    const float wy = interp_axis_weight(ho, y, sy, H);
+    if (wy == 0.f) continue;
+    float row = 0.f;
+    for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+      const float wx = interp_axis_weight(wo, x, sx, W);
+      if (wx != 0.f) row += wx * rc_to_float(src[(int64_t)ho * Wo + wo]);
+    }
+    acc += wy * row;
+  }
+  dx[idx] = rc_from_float<T>(acc);
+}
+
+template <typename T>
+int launch_resample_bwd(int which, const void* g, void* dx, int64_t N, int64_t C, int64_t H, int64_t W, int64_t Ho,
+                        int64_t Wo, hipStream_t st) {
+  const int64_t total = N * C * H * W;
+  const int64_t nb = (total + PW_THREADS - 1) / PW_THREADS;
+  RC_REQUIRE(nb < (1ll << 31), RC_EINVAL, "too many elements");
+  if (which == 0) {
+    hipLaunchKernelGGL((pool2x_bwd_kernel<T>), dim3((unsigned)nb), dim3(PW_THREADS), 0, st, (const T*)g, (T*)dx, (int)H,
+                       (int)W, (int)Ho, (int)Wo, total);
+    return rc_check_launch("rc_pool2x_bwd");
+  }
+  const float sy = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, sx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+  hipLaunchKernelGGL((interp_bwd_kernel<T>), dim3((unsigned)nb), dim3(PW_THREADS), 0, st, (const T*)g, (T*)dx, (int)H,
+                     (int)W, (int)Ho, (int)Wo, sy, sx, sy > 0.f ? 1.0f / sy : 0.f, sx > 0.f ? 1.0f / sx : 0.f, total);
+  return rc_check_launch("rc_interp_bilinear_bwd");
+}
+
+int resample_bwd_any(int which, const void* g, void* dx, int64_t N, int64_t C, int64_t H, int64_t W, int64_t Ho,
+                     int64_t Wo, int dtype, void* stream) {
+  RC_REQUIRE(g && dx, RC_EINVAL, "null pointer argument");
+  RC_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && H < (1 << 24) && W < (1 << 24), RC_EINVAL,
+             "bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  switch (dtype) {
+    case RC_F32: return launch_resample_bwd<float>(which, g, dx, N, C, H, W, Ho, Wo, st);
+    case RC_F16: return launch_resample_bwd<rc_half>(which, g, dx, N, C, H, W, Ho, Wo, st);
+    case RC_BF16: return launch_resample_bwd<rc_bf16>(which, g, dx, N, C, H, W, Ho, Wo, st);
+  }
+  rc_set_error("unknown dtype %d", dtype);
+  return RC_EUNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" int rc_pool2x_bwd(const void* grad_out, void* grad_x, int64_t N, int64_t C, int64_t H, int64_t W,
+                             int dtype, void* stream) {
+  return resample_bwd_any(0, grad_out, grad_x, N, C, H, W, (H - 1) / 2 + 1, (W - 1) / 2 + 1, dtype, stream);
+}
+
+extern "C" int rc_interp_bilinear_bwd(const void* grad_out, void* grad_x, int64_t N, int64_t C, int64_t H, int64_t W,
+                                      int64_t Ho, int64_t Wo, int dtype, void* stream) {
+  return resample_bwd_any(1, grad_out, grad_x, N, C, H, W, Ho, Wo, dtype, stream);
+}

@@ -203,35 +203,66 @@ class ConvGRUHip(nn.Module):
 
 
 def _resample_ok(x):
-    return x.is_cuda and x.dim() == 4 and x.dtype in _DT and not (torch.is_grad_enabled() and x.requires_grad)
+    return x.is_cuda and x.dim() == 4 and x.dtype in _DT
+
+
+class _Pool2xFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        N, C, H, W = x.shape
+        out = torch.empty((N, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=x.dtype, device=x.device)
+        with _on_device(x.device):
+            check(lib.rc_pool2x(x.data_ptr(), out.data_ptr(), N, C, H, W, out[0].numel(), _DT[x.dtype],
+                                _stream(x.device)), "rc_pool2x")
+        ctx.shape = (N, C, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        N, C, H, W = ctx.shape
+        g = grad_out.contiguous()
+        dx = torch.empty((N, C, H, W), dtype=g.dtype, device=g.device)
+        with _on_device(g.device):
+            check(lib.rc_pool2x_bwd(g.data_ptr(), dx.data_ptr(), N, C, H, W, _DT[g.dtype], _stream(g.device)),
+                  "rc_pool2x_bwd")
+        return dx
+
+
+class _InterpFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, Ho, Wo):
+        N, C, H, W = x.shape
+        out = torch.empty((N, C, Ho, Wo), dtype=x.dtype, device=x.device)
+        with _on_device(x.device):
+            check(lib.rc_interp_bilinear(x.data_ptr(), out.data_ptr(), N, C, H, W, Ho, Wo, out[0].numel(),
+                                         _DT[x.dtype], _stream(x.device)), "rc_interp_bilinear")
+        ctx.shape = (N, C, H, W, Ho, Wo)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        N, C, H, W, Ho, Wo = ctx.shape
+        g = grad_out.contiguous()
+        dx = torch.empty((N, C, H, W), dtype=g.dtype, device=g.device)
+        with _on_device(g.device):
+            check(lib.rc_interp_bilinear_bwd(g.data_ptr(), dx.data_ptr(), N, C, H, W, Ho, Wo, _DT[g.dtype],
+                                             _stream(g.device)), "rc_interp_bilinear_bwd")
+        return dx, None, None
 
 
 def pool2x_hip(x):
-    """`F.avg_pool2d(x, 3, stride=2, padding=1)` (core/update.py:87-88) in the library.  Forward only."""
+    """`F.avg_pool2d(x, 3, stride=2, padding=1)` (core/update.py:87-88) in the library, differentiable."""
     if not _resample_ok(x):
-        raise RuntimeError("pool2x_hip needs a GPU [N,C,H,W] tensor outside autograd")
-    x = x.contiguous()
-    N, C, H, W = x.shape
-    out = torch.empty((N, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=x.dtype, device=x.device)
-    with _on_device(x.device):
-        check(lib.rc_pool2x(x.data_ptr(), out.data_ptr(), N, C, H, W, out[0].numel(), _DT[x.dtype],
-                            _stream(x.device)), "rc_pool2x")
-    return out
+        raise RuntimeError("pool2x_hip needs a GPU [N,C,H,W] tensor (there is no CPU path)")
+    return _Pool2xFn.apply(x.contiguous())
 
 
 def interp_hip(x, dest):
     """`F.interpolate(x, dest.shape[2:], mode='bilinear', align_corners=True)` (core/update.py:93-95) in the
-    library, in x's own type (fp32 arithmetic).  Forward only."""
+    library, in x's own type (fp32 arithmetic), differentiable."""
     if not _resample_ok(x):
-        raise RuntimeError("interp_hip needs a GPU [N,C,H,W] tensor outside autograd")
-    x = x.contiguous()
-    N, C, H, W = x.shape
-    Ho, Wo = int(dest.shape[2]), int(dest.shape[3])
-    out = torch.empty((N, C, Ho, Wo), dtype=x.dtype, device=x.device)
-    with _on_device(x.device):
-        check(lib.rc_interp_bilinear(x.data_ptr(), out.data_ptr(), N, C, H, W, Ho, Wo, out[0].numel(), _DT[x.dtype],
-                                     _stream(x.device)), "rc_interp_bilinear")
-    return out
+        raise RuntimeError("interp_hip needs a GPU [N,C,H,W] tensor (there is no CPU path)")
+    return _InterpFn.apply(x.contiguous(), int(dest.shape[2]), int(dest.shape[3]))
 
 
 class _UpsampleFn(torch.autograd.Function):

@@ -8,8 +8,8 @@ package's kernels (core/update.py:64-138 of the reference).
 
 What runs in the HIP library: the three ConvGRUs' gate arithmetic (ConvGRUHip) and, when the caller hands
 over the correlation block and the coordinates instead of a looked-up `corr` tensor, the lookup fused with
-the motion encoder's first layer (`corr_fn.lookup_convc1`), and in inference the pooling / bilinear resizing
-between the scales.  The dense convolutions are torch's, as in the reference.
+the motion encoder's first layer (`corr_fn.lookup_convc1`), and the pooling / bilinear resizing between the
+scales.  The dense convolutions are torch's, as in the reference.
 """
 import torch
 import torch.nn as nn
@@ -19,7 +19,7 @@ from raft_stereo_amd.update import ConvGRUHip, _resample_ok, interp_hip, pool2x_
 
 
 def _down2(x):
-    if _resample_ok(x):                                                 # inference: the library's kernel
+    if _resample_ok(x):                                                 # the library's kernel (and its adjoint)
         return pool2x_hip(x)
     return F.avg_pool2d(x, 3, stride=2, padding=1)                      # update.py:87-88
 

@@ -108,13 +108,19 @@ def run_resample(seed):
     torch.manual_seed(seed)
     rec = {}
     for i, shp in enumerate([(2, 5, 7, 9), (1, 3, 8, 12), (1, 2, 1, 5), (1, 4, 12, 80)]):
-        x = torch.randn(shp)
-        rec[f"pool_in{i}"], rec[f"pool_out{i}"] = x, pool2x(x)
+        x = torch.randn(shp).requires_grad_(True)
+        y = pool2x(x)
+        g = torch.randn(y.shape)
+        y.backward(g)
+        rec[f"pool_in{i}"], rec[f"pool_out{i}"], rec[f"pool_cot{i}"], rec[f"pool_grad{i}"] = x, y, g, x.grad
     for i, (shp, dst) in enumerate([((1, 3, 4, 6), (8, 12)), ((2, 5, 4, 5), (7, 9)), ((1, 2, 3, 3), (3, 3)),
                                     ((1, 4, 6, 40), (12, 80)), ((1, 2, 2, 2), (1, 5))]):
-        x = torch.randn(shp)
-        rec[f"interp_in{i}"], rec[f"interp_out{i}"] = x, interp(x, torch.empty(1, 1, *dst))
-    return {k: v.numpy().copy() for k, v in rec.items()}
+        x = torch.randn(shp).requires_grad_(True)
+        y = interp(x, torch.empty(1, 1, *dst))
+        g = torch.randn(y.shape)
+        y.backward(g)
+        rec[f"interp_in{i}"], rec[f"interp_out{i}"], rec[f"interp_cot{i}"], rec[f"interp_grad{i}"] = x, y, g, x.grad
+    return {k: v.detach().numpy().copy() for k, v in rec.items()}
 
 
 if __name__ == "__main__":

@@ -401,6 +401,34 @@ def test_pool2x_and_interp_match_reference(R, golden, dtype):
             assert rel(out, ref) < tol, k
 
 
+def test_pool2x_and_interp_backward_match_reference_autograd(R, golden):
+    g = golden("update_resample")
+    for k in [k for k in g if k.startswith("pool_in")]:
+        i = k[len("pool_in"):]
+        x = dev(g[k]).requires_grad_(True)
+        R.pool2x_hip(x).backward(dev(g["pool_cot" + i]))
+        assert rel(x.grad, g["pool_grad" + i]) < TOL32, k
+    for k in [k for k in g if k.startswith("interp_in")]:
+        i = k[len("interp_in"):]
+        x = dev(g[k]).requires_grad_(True)
+        R.interp_hip(x, torch.empty(1, 1, *g["interp_out" + i].shape[2:])).backward(dev(g["interp_cot" + i]))
+        assert rel(x.grad, g["interp_grad" + i]) < TOL32, k
+    # model size, 16-bit: against torch's own backward
+    torch.manual_seed(14)
+    lo = torch.randn(2, 128, 40, 90, device="cuda").half().requires_grad_(True)
+    cot = torch.randn(2, 128, 80, 180, device="cuda").half()
+    R.interp_hip(lo, cot).backward(cot)
+    ref = lo.detach().float().requires_grad_(True)
+    torch.nn.functional.interpolate(ref, (80, 180), mode="bilinear", align_corners=True).backward(cot.float())
+    assert rel(lo.grad, ref.grad.cpu().numpy()) < TOL16[torch.float16]
+    hi = torch.randn(2, 128, 80, 180, device="cuda").half().requires_grad_(True)
+    cot = torch.randn(2, 128, 40, 90, device="cuda").half()
+    R.pool2x_hip(hi).backward(cot)
+    ref = hi.detach().float().requires_grad_(True)
+    torch.nn.functional.avg_pool2d(ref, 3, stride=2, padding=1).backward(cot.float())
+    assert rel(hi.grad, ref.grad.cpu().numpy()) < TOL16[torch.float16]
+
+
 def test_pool2x_and_interp_equal_torch_at_model_size(R):
     """net[0] -> 1/8 resolution and net[1] -> 1/4 resolution of the KITTI share, against torch's own kernels."""
     torch.manual_seed(12)

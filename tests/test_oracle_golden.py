@@ -231,6 +231,10 @@ def test_pool2x_and_interp_match_reference(golden):
     g = golden("update_resample")
     for k in [k for k in g if k.startswith("pool_in")]:
         assert U.rel_to_max(U.pool2x(g[k]), g["pool_out" + k[len("pool_in"):]]) <= 1e-6, k
+        i = k[len("pool_in"):]
+        assert U.rel_to_max(U.pool2x_bwd(g["pool_cot" + i], *g[k].shape[2:]), g["pool_grad" + i]) <= 1e-6, k
     for k in [k for k in g if k.startswith("interp_in")]:
         ref = g["interp_out" + k[len("interp_in"):]]
         assert U.rel_to_max(U.interp(g[k], *ref.shape[2:]), ref) <= 1e-6, k
+        i = k[len("interp_in"):]
+        assert U.rel_to_max(U.interp_bwd(g["interp_cot" + i], *g[k].shape[2:]), g["interp_grad" + i]) <= 1e-5, k
