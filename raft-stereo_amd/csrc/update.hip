@@ -1011,40 +1011,82 @@ __global__ __launch_bounds__(PW_THREADS) void pool2x_kernel(const T* __restrict_
   *reinterpret_cast<typename pw_vec<T, VEC>::type*>(out + n * out_bs + (c * Ho + ho) * (int64_t)Wo + wo0) = o;
 }
 
+// One thread = VEC consecutive outputs of INTERP_ROWS consecutive output rows.  The horizontal blends of an input
+// row are kept in registers and reused by every output row between the same two input rows (when upsampling by
+// two, 4 output rows read 3 input rows instead of 8); each value is computed by the same expression whichever
+// output row asks first, so the result does not depend on the grouping.
+constexpr int INTERP_ROWS = 4;
+
 template <typename T, int VEC>
 __global__ __launch_bounds__(PW_THREADS) void interp_kernel(const T* __restrict__ x, T* __restrict__ out, int H, int W,
                                                             int Ho, int Wo, int C, int64_t out_bs, float sy, float sx,
                                                             int64_t total) {
   const int64_t v = (int64_t)blockIdx.x * PW_THREADS + threadIdx.x;
   if (v >= total) return;
-  const int wv = Wo / VEC;
+  const int wv = Wo / VEC, hg = (Ho + INTERP_ROWS - 1) / INTERP_ROWS;
   const int wo0 = (int)(v % wv) * VEC;
   const int64_t r = v / wv;
-  const int ho = (int)(r % Ho);
-  const int64_t nc = r / Ho, n = nc / C, c = nc - n * C;
+  const int ho0 = (int)(r % hg) * INTERP_ROWS;
+  const int64_t nc = r / hg, n = nc / C, c = nc - n * C;
+  const T* src = x + nc * (int64_t)H * W;
   // align_corners=True: source position = destination index * (in - 1) / (out - 1), in fp32 like torch
-  const float fy = sy * (float)ho;
-  const int y0 = min((int)fy, H - 1), y1 = min(y0 + 1, H - 1);
-  const float ly = fy - (float)y0, hy = 1.0f - ly;
-  const T* r0 = x + nc * (int64_t)H * W + (int64_t)y0 * W;
-  const T* r1 = x + nc * (int64_t)H * W + (int64_t)y1 * W;
-  typename pw_vec<T, VEC>::type o;
+  int x0[VEC], x1[VEC];
+  float lx[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
     const float fx = sx * (float)(wo0 + j);
-    const int x0 = min((int)fx, W - 1), x1 = min(x0 + 1, W - 1);
-    const float lx = fx - (float)x0, hx = 1.0f - lx;
-    const float top = hx * rc_to_float(r0[x0]) + lx * rc_to_float(r0[x1]);
-    const float bot = hx * rc_to_float(r1[x0]) + lx * rc_to_float(r1[x1]);
-    o[j] = rc_from_float<T>(hy * top + ly * bot);
+    x0[j] = min((int)fx, W - 1);
+    x1[j] = min(x0[j] + 1, W - 1);
+    lx[j] = fx - (float)x0[j];
   }
-  *reinterpret_cast<typename pw_vec<T, VEC>::type*>(out + n * out_bs + (c * Ho + ho) * (int64_t)Wo + wo0) = o;
+  auto blend_row = [&](int y, float* h) {
+    const T* row = src + (int64_t)y * W;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const float hx = 1.0f - lx[j];
+      h[j] = hx * rc_to_float(row[x0[j]]) + lx[j] * rc_to_float(row[x1[j]]);
+    }
+  };
+  float top[VEC], bot[VEC];
+  int ty = -1, by = -1;  // the input rows `top` and `bot` hold
+  T* dst = out + n * out_bs + c * (int64_t)Ho * Wo + wo0;
+#pragma unroll
+  for (int k = 0; k < INTERP_ROWS; ++k) {
+    const int ho = ho0 + k;
+    if (ho >= Ho) break;
+    const float fy = sy * (float)ho;
+    const int y0 = min((int)fy, H - 1), y1 = min(y0 + 1, H - 1);
+    const float ly = fy - (float)y0, hy = 1.0f - ly;
+    if (y0 != ty) {
+      if (y0 == by) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) top[j] = bot[j];
+      } else {
+        blend_row(y0, top);
+      }
+      ty = y0;
+    }
+    if (y1 != by) {
+      if (y1 == ty) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) bot[j] = top[j];
+      } else {
+        blend_row(y1, bot);
+      }
+      by = y1;
+    }
+    typename pw_vec<T, VEC>::type o;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) o[j] = rc_from_float<T>(hy * top[j] + ly * bot[j]);
+    *reinterpret_cast<typename pw_vec<T, VEC>::type*>(dst + (int64_t)ho * Wo) = o;
+  }
 }
 
 template <typename T, int V>
 int launch_resample_v(int which, const void* x, void* out, int64_t N, int64_t C, int64_t H, int64_t W, int64_t Ho,
                       int64_t Wo, int64_t out_bs, hipStream_t st) {
-  const int64_t total = N * C * Ho * (Wo / V);
+  const int64_t rows = which == 0 ? Ho : (Ho + INTERP_ROWS - 1) / INTERP_ROWS;  // interp: a thread walks 4 rows
+  const int64_t total = N * C * rows * (Wo / V);
   const int64_t nb = (total + PW_THREADS - 1) / PW_THREADS;
   RC_REQUIRE(nb < (1ll << 31), RC_EINVAL, "too many elements");
   const dim3 grid((unsigned)nb);
