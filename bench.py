@@ -396,7 +396,7 @@ def _torch_ops_refine(blk, corr_fn, net_list, inp_list, args, iters, test_mode=T
     return (fl, preds[-1]) if test_mode else preds
 
 
-def refine_loop(step, cfg, device, reps=3, capture=True):
+def refine_loop(step, cfg, device, reps=3, capture=True, baseline=True):
     """Everything RAFTStereo.forward does after its encoders (core/raft_stereo.py:100-141) on this package's
     operators, beside the contract's metric: correlation block + default-width update block (hidden 128, 3 GRU
     layers; its dense convolutions are torch's) + convex upsampling, test mode, autocast for 16-bit feature maps.
@@ -429,6 +429,9 @@ def refine_loop(step, cfg, device, reps=3, capture=True):
             once()
         torch.cuda.synchronize()
         dt_s = (time.perf_counter() - t0) / reps
+    if not baseline:      # --loop-only: a kernel trace of the library's loop alone
+        return dict(refine_loop_ms=round(dt_s * 1e3, 2))
+
     def once_torch():
         corr_fn = step.cls(step.f1, step.f2, num_levels=LEVELS, radius=RADIUS)
         return _torch_ops_refine(blk, corr_fn, net, inp, args, iters)
@@ -600,6 +603,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-refine-loop", action="store_true",
                     help="skip the refinement-loop side metric (torch convolutions, HIP graph capture): for profiler runs")
+    ap.add_argument("--loop-only", action="store_true",
+                    help="after the timed region run only the library's refine loop (no torch-ops leg, no side metrics)")
     ap.add_argument("--adversarial", action="store_true", help="i.i.d. uniform disparity (worst-case gather)")
     args = ap.parse_args()
 
@@ -682,15 +687,19 @@ def main():
     if cfg["train"]:
         extra.update(backward_ms=round(float(np.median(step.bwd_ms)), 4))
 
-    if not is_alt and not cfg["train"] and rank == 0:
+    if args.loop_only:
+        if rank == 0 and not cfg["train"]:
+            extra.update(refine_loop(step, cfg, device, capture=False, baseline=False))
+    elif not is_alt and not cfg["train"] and rank == 0:
         extra.update(fused_convc1(step, cfg, device))      # after the timed region: not part of `value`
-    if rank == 0 and cfg["H"] * cfg["W"] * cfg["batch"] <= 300000:
+    if not args.loop_only and rank == 0 and cfg["H"] * cfg["W"] * cfg["batch"] <= 300000:
         extra.update(update_ops(cfg, device))              # side metrics, after the timed region
-    if not cfg["train"] and rank == 0 and cfg["H"] * cfg["W"] * cfg["batch"] <= 300000 and not args.no_refine_loop:
+    if (not args.loop_only and not cfg["train"] and rank == 0 and cfg["H"] * cfg["W"] * cfg["batch"] <= 300000
+            and not args.no_refine_loop):
         extra.update(refine_loop(step, cfg, device, capture=world == 1))
-    if cfg["train"] and rank == 0 and not args.no_refine_loop:
+    if cfg["train"] and rank == 0 and not args.no_refine_loop and not args.loop_only:
         extra.update(refine_train_step(step, cfg, device))
-    if not cfg["train"] and world == 1:       # side metric; kept out of multi-rank runs (no capture beside RCCL)
+    if not cfg["train"] and world == 1 and not args.loop_only:       # side metric; kept out of multi-rank runs (no capture beside RCCL)
         extra.update(hip_graph_step(step))
 
     if not args.dtype and not args.adversarial:     # the committed profiles are of the stock workloads

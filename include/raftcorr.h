@@ -304,6 +304,17 @@ int rc_interp_bilinear_bwd(const void* grad_out, void* grad_x, int64_t N, int64_
                            int64_t W, int64_t Ho, int64_t Wo, int dtype, void* stream);
 
 /*
+ * Epilogue of the update block's dense convolutions in inference (core/update.py:13,77-84,133-137: every
+ * `conv(x)` adds its bias, most are followed by F.relu): x = act(x + bias[c]) in place, x [N,C,HW] contiguous
+ * of `dtype` (the output of a bias-free convolution), bias [C] of bias_dtype (x's type, or RC_F32: the
+ * fp32 parameter under autocast, rounded to x's type first as autocast's cast does); relu != 0 applies
+ * max(., 0) keeping NaN.  Replaces the separate broadcast add_ and ReLU passes torch's MIOpen path runs,
+ * with their roundings (sum rounded to `dtype`).
+ */
+int rc_bias_act(void* x, const void* bias, int bias_dtype, int64_t N, int64_t C, int64_t HW, int dtype,
+                int relu, void* stream);
+
+/*
  * SURVEY.md section 8(f) rank 4 -- convex upsampling, RAFTStereo.upsample_flow (core/raft_stereo.py:55-67):
  *     out[n, c, f*h + fy, f*w + fx] = sum_k softmax_k(mask[n, k, fy, fx, h, w]) * f * flow[n, c, h + k/3 - 1, w + k%3 - 1]
  * (zeros outside the image, F.unfold padding=1).  flow: float [N, >=channels, H, W], the first `channels`

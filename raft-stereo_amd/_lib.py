@@ -75,6 +75,7 @@ SIGNATURES = {
     "rc_interp_bilinear": (_I, [_P, _P, _L, _L, _L, _L, _L, _L, _L, _I, _P]),
     "rc_pool2x_bwd": (_I, [_P, _P, _L, _L, _L, _L, _I, _P]),
     "rc_interp_bilinear_bwd": (_I, [_P, _P, _L, _L, _L, _L, _L, _L, _I, _P]),
+    "rc_bias_act": (_I, [_P, _P, _I, _L, _L, _L, _I, _I, _P]),
     "rc_upsample_flow_fwd": (_I, [_P, _L, _P, _P, _L, _I, _L, _L, _I, _I, _P]),
     "rc_upsample_flow_bwd_work_bytes": (_L, [_L, _I, _L, _L]),
     "rc_upsample_flow_bwd": (_I, [_P, _L, _P, _P, _P, _P, _L, _P, _L, _I, _L, _L, _I, _I, _P]),

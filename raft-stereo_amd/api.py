@@ -1,7 +1,7 @@
 """Public names of the package."""
 from raft_stereo_amd.corr import (CorrBlock1DHip, AltCorrBlock1DHip, CorrSamplerHip)
 from raft_stereo_amd import sampler as corr_sampler_hip
-from raft_stereo_amd.update import (ConvGRUHip, gru_gate_r, gru_update, upsample_flow_hip, sequence_loss_hip,
+from raft_stereo_amd.update import (ConvGRUHip, bias_act_, conv_bias_act, gru_gate_r, gru_update, upsample_flow_hip, sequence_loss_hip,
                                     pool2x_hip, interp_hip)
 from raft_stereo_amd.update_block import BasicMultiUpdateBlockHip, MotionEncoderHip
 from raft_stereo_amd.refine import refine_disparity
@@ -9,6 +9,6 @@ from raft_stereo_amd.dispatch import (CORR_IMPLEMENTATIONS, HIP_CORR_CHOICES, ma
                                       wants_autocast, shard_rows, shard_pairs)
 
 __all__ = ["CorrBlock1DHip", "AltCorrBlock1DHip", "CorrSamplerHip",
-           "ConvGRUHip", "gru_gate_r", "gru_update", "upsample_flow_hip", "sequence_loss_hip", "pool2x_hip", "interp_hip", "BasicMultiUpdateBlockHip", "MotionEncoderHip", "refine_disparity",
+           "ConvGRUHip", "bias_act_", "conv_bias_act", "gru_gate_r", "gru_update", "upsample_flow_hip", "sequence_loss_hip", "pool2x_hip", "interp_hip", "BasicMultiUpdateBlockHip", "MotionEncoderHip", "refine_disparity",
            "corr_sampler_hip", "CORR_IMPLEMENTATIONS", "HIP_CORR_CHOICES", "make_corr_fn",
            "wants_autocast", "shard_rows", "shard_pairs"]

@@ -1145,6 +1145,75 @@ extern "C" int rc_interp_bilinear(const void* x, void* out, int64_t N, int64_t C
   return resample_any(1, x, out, N, C, H, W, Ho, Wo, out_batch_stride, dtype, stream);
 }
 
+// ---- convolution epilogue (inference): x = act(x + bias[c]) in place.  torch's MIOpen path adds a convolution's
+// bias as a separate broadcast add_ (a strided-iterator kernel) and the ReLU after it as another pass; this is both
+// in one pass of 16-byte accesses with the same roundings: the bias is rounded to x's type first (what autocast's
+// cast of the parameter gives), the sum is rounded to x's type, ReLU keeps NaN.
+namespace {
+
+template <typename T, typename BT, int VEC>
+__global__ __launch_bounds__(PW_THREADS) void bias_act_kernel(T* __restrict__ x, const BT* __restrict__ bias, int C,
+                                                              int64_t hwv, int relu, int64_t total) {
+  const int64_t v = (int64_t)blockIdx.x * PW_THREADS + threadIdx.x;
+  if (v >= total) return;
+  const int c = (int)((v / hwv) % C);
+  const float b = rnd<T>(rc_to_float(bias[c]));
+  auto* p = reinterpret_cast<typename pw_vec<T, VEC>::type*>(x) + v;
+  auto val = *p;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    float f = rnd<T>(rc_to_float(val[j]) + b);
+    if (relu) f = f < 0.f ? 0.f : f;
+    val[j] = rc_from_float<T>(f);
+  }
+  *p = val;
+}
+
+template <typename T, typename BT, int V>
+int launch_bias_act_v(void* x, const void* bias, int64_t N, int64_t C, int64_t HW, int relu, hipStream_t st) {
+  const int64_t total = N * C * (HW / V);
+  const int64_t nb = (total + PW_THREADS - 1) / PW_THREADS;
+  RC_REQUIRE(nb < (1ll << 31), RC_EINVAL, "too many elements");
+  hipLaunchKernelGGL((bias_act_kernel<T, BT, V>), dim3((unsigned)nb), dim3(PW_THREADS), 0, st, (T*)x, (const BT*)bias,
+                     (int)C, HW / V, relu, total);
+  return rc_check_launch("rc_bias_act");
+}
+
+template <typename T, typename BT>
+int launch_bias_act(void* x, const void* bias, int64_t N, int64_t C, int64_t HW, int relu, hipStream_t st) {
+  constexpr int V = 16 / (int)sizeof(T);
+  auto fits = [&](int v) { return HW % v == 0 && (uintptr_t)x % (v * sizeof(T)) == 0; };
+  if (fits(V)) return launch_bias_act_v<T, BT, V>(x, bias, N, C, HW, relu, st);
+  if (fits(V / 2)) return launch_bias_act_v<T, BT, V / 2>(x, bias, N, C, HW, relu, st);
+  if constexpr (V >= 8) {
+    if (fits(V / 4)) return launch_bias_act_v<T, BT, V / 4>(x, bias, N, C, HW, relu, st);
+  }
+  return launch_bias_act_v<T, BT, 1>(x, bias, N, C, HW, relu, st);
+}
+
+}  // namespace
+
+extern "C" int rc_bias_act(void* x, const void* bias, int bias_dtype, int64_t N, int64_t C, int64_t HW, int dtype,
+                           int relu, void* stream) {
+  RC_REQUIRE(x && bias, RC_EINVAL, "null pointer argument");
+  RC_REQUIRE(N > 0 && C > 0 && C < (1 << 30) && HW > 0, RC_EINVAL, "bad sizes");
+  RC_REQUIRE(bias_dtype == dtype || bias_dtype == RC_F32, RC_EUNSUPPORTED,
+             "the bias must have x's type or be RC_F32 (got %d for x of type %d)", bias_dtype, dtype);
+  hipStream_t st = (hipStream_t)stream;
+  const bool bf = bias_dtype == RC_F32;
+  switch (dtype) {
+    case RC_F32: return launch_bias_act<float, float>(x, bias, N, C, HW, relu, st);
+    case RC_F16:
+      return bf ? launch_bias_act<rc_half, float>(x, bias, N, C, HW, relu, st)
+                : launch_bias_act<rc_half, rc_half>(x, bias, N, C, HW, relu, st);
+    case RC_BF16:
+      return bf ? launch_bias_act<rc_bf16, float>(x, bias, N, C, HW, relu, st)
+                : launch_bias_act<rc_bf16, rc_bf16>(x, bias, N, C, HW, relu, st);
+  }
+  rc_set_error("unknown dtype %d", dtype);
+  return RC_EUNSUPPORTED;
+}
+
 // ---- adjoints of the between-scale glue (training): gathers, no atomics.  One thread per INPUT element.
 namespace {
 

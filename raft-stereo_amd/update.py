@@ -149,6 +149,40 @@ def gru_update(convz_out, cz, convq_out, cq, h):
     return out
 
 
+def bias_act_(y, bias, relu=False):
+    """In place `y = act(y + bias[c])` on a bias-free convolution's output [N,C,H,W] (rc_bias_act): one pass
+    instead of torch's broadcast add_ and ReLU, same roundings.  Inference only."""
+    if not y.is_cuda or y.dtype not in _DT or y.dim() != 4 or not y.is_contiguous():
+        raise RuntimeError("bias_act_ needs a contiguous GPU [N,C,H,W] tensor (there is no CPU path)")
+    if bias.dtype not in (y.dtype, torch.float32) or bias.numel() != y.shape[1] or not bias.is_contiguous():
+        raise ValueError("bias must be a contiguous [C] tensor of y's type or fp32")
+    if torch.is_grad_enabled() and (y.requires_grad or bias.requires_grad):
+        raise RuntimeError("bias_act_ writes in place and is forward-only")
+    N, C, H, W = y.shape
+    if y.numel():
+        with _on_device(y.device):
+            check(lib.rc_bias_act(y.data_ptr(), bias.data_ptr(), _DT[bias.dtype], N, C, H * W, _DT[y.dtype],
+                                  int(bool(relu)), _stream(y.device)), "rc_bias_act")
+    return y
+
+
+def conv_bias_act(conv, x, relu=False):
+    """`conv(x)` / `F.relu(conv(x))` of an nn.Conv2d.  In inference on the GPU the convolution runs without its
+    bias and the library adds bias and ReLU in one in-place pass; with gradients (or anything the kernel does not
+    take) it is the torch expression itself."""
+    plain = (conv.bias is None or not x.is_cuda or conv.padding_mode != "zeros"
+             or (torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad or conv.bias.requires_grad)))
+    if not plain:
+        y = nn.functional.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+        bias = conv.bias.detach()
+        if y.dtype in _DT and y.is_contiguous() and bias.dtype in (y.dtype, torch.float32):
+            return bias_act_(y, bias, relu)
+        y = y + bias.to(y.dtype).view(1, -1, 1, 1)
+        return torch.relu(y) if relu else y
+    y = conv(x)
+    return torch.relu(y) if relu else y
+
+
 class ConvGRUHip(nn.Module):
     """Drop-in for the reference's ConvGRU (core/update.py:16-32): same constructor, same parameter names
     (a reference state_dict loads as is), same `forward(h, cz, cr, cq, *x_list)`.  convz and convr read the
@@ -196,9 +230,9 @@ class ConvGRUHip(nn.Module):
             return gru_update(zr[:, :C], cz, qc.to(dt), cq, h)                    # update.py:27,29,31
         with torch.no_grad():
             w, b = self._stacked(dt)
-            zr = nn.functional.conv2d(hx, w, b, padding=self.convz.padding)
+            zr = bias_act_(nn.functional.conv2d(hx, w, None, padding=self.convz.padding), b)
             gru_gate_r(zr[:, C:], cr, h, out=hx[:, :C])   # hx is this call's own copy; both convolutions have read it
-            qc = self.convq(hx)
+            qc = conv_bias_act(self.convq, hx)
             return gru_update(zr[:, :C], cz, qc.to(dt), cq, h)
 
 

@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from raft_stereo_amd.update import ConvGRUHip, _resample_ok, interp_hip, pool2x_hip
+from raft_stereo_amd.update import ConvGRUHip, _resample_ok, conv_bias_act, interp_hip, pool2x_hip
 
 
 def _down2(x):
@@ -52,9 +52,9 @@ class MotionEncoderHip(nn.Module):
                 c = c.to(self.convc2.weight.dtype)
         else:
             c = F.relu(self.convc1(corr))
-        c = F.relu(self.convc2(c))
-        f = F.relu(self.convf2(F.relu(self.convf1(flow))))
-        both = F.relu(self.conv(torch.cat([c, f.to(c.dtype)], dim=1)))
+        c = conv_bias_act(self.convc2, c, relu=True)
+        f = conv_bias_act(self.convf2, conv_bias_act(self.convf1, flow, relu=True), relu=True)
+        both = conv_bias_act(self.conv, torch.cat([c, f.to(c.dtype)], dim=1), relu=True)
         # under autocast the reference's concatenation promotes to fp32 and the GRU's convolutions cast back;
         # casting the two flow planes instead gives the same values without the fp32 round trip of 126 planes
         return torch.cat([both, flow.to(both.dtype) if torch.is_autocast_enabled() else flow], dim=1)
@@ -69,7 +69,7 @@ class FlowHeadHip(nn.Module):
         self.conv2 = nn.Conv2d(hidden_dim, output_dim, 3, padding=1)
 
     def forward(self, x):
-        return self.conv2(F.relu(self.conv1(x)))
+        return conv_bias_act(self.conv2, conv_bias_act(self.conv1, x, relu=True))
 
 
 class BasicMultiUpdateBlockHip(nn.Module):
@@ -103,5 +103,5 @@ class BasicMultiUpdateBlockHip(nn.Module):
         if not update:
             return net
         delta_flow = self.flow_head(net[0])
-        mask = .25 * self.mask(net[0])             # scaled to balance gradients (update.py:136-137)
+        mask = .25 * conv_bias_act(self.mask[2], conv_bias_act(self.mask[0], net[0], relu=True))   # update.py:136-137
         return net, mask, delta_flow

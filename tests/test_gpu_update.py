@@ -499,3 +499,41 @@ def test_update_argument_errors(R):
     assert lib.rc_upsample_flow_fwd(None, 0, None, None, 1, 1, 1, 1, 4, 0, None) != 0
     assert lib.rc_upsample_flow_fwd(1, 8, 1, 16, 1, 2, 2, 2, 3, 0, None) != 0      # factor 3
     assert lib.rc_gru_update(None, 0, None, 0, None, 0, None, 0, None, None, 1, 1, 0, None) != 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("hw", [(12, 40), (7, 13), (5, 6), (3, 12)])      # 16-, 2-, 4- and 8-byte accesses at fp16
+def test_bias_act_equals_torch_add_and_relu_bit_for_bit(R, dtype, hw):
+    """rc_bias_act against the two torch passes it replaces (broadcast add_ of the bias cast to the tensor's
+    type, then relu): same roundings, so the bar is equality; fp32 and same-type bias, NaN kept."""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn((3, 10, *hw), generator=g, device="cuda").to(dtype)
+    x[0, 0, 0, 0] = float("nan")
+    b32 = torch.randn(10, generator=g, device="cuda")
+    for bias in (b32, b32.to(dtype)):
+        for relu in (False, True):
+            want = x + bias.to(dtype).view(1, -1, 1, 1)
+            want = torch.relu(want) if relu else want
+            got = R.bias_act_(x.clone(), bias, relu)
+            assert torch.equal(torch.nan_to_num(got, nan=123.0), torch.nan_to_num(want, nan=123.0))
+            assert torch.isnan(got[0, 0, 0, 0])
+
+
+@pytest.mark.parametrize("amp", [False, True])
+def test_conv_bias_act_equals_the_module_call(R, amp):
+    """conv_bias_act(conv, x, relu) against F.relu(conv(x)) with torch's own bias handling, fp32 and autocast."""
+    torch.manual_seed(0)
+    conv = torch.nn.Conv2d(24, 40, 3, padding=1).cuda()
+    x = torch.randn(2, 24, 20, 36, device="cuda")
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+        for relu in (False, True):
+            want = conv(x)
+            want = torch.relu(want) if relu else want
+            got = R.conv_bias_act(conv, x, relu)
+            assert got.dtype == want.dtype
+            # the bias-free convolution may pick another MIOpen solver than the biased call: value bar, not bits
+            assert rel(got, want.float().cpu().numpy()) <= (2e-3 if amp else TOL_CONV)
+    # with gradients it is the torch expression itself
+    y = R.conv_bias_act(conv, x.requires_grad_(True), True)
+    y.sum().backward()
+    assert conv.bias.grad is not None and x.grad is not None
