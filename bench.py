@@ -603,10 +603,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-refine-loop", action="store_true",
                     help="skip the refinement-loop side metric (torch convolutions, HIP graph capture): for profiler runs")
+    ap.add_argument("--miopen-find", action="store_true",
+                    help="torch.backends.cudnn.benchmark = True: MIOpen searches its solvers for the loop's convolutions")
     ap.add_argument("--loop-only", action="store_true",
                     help="after the timed region run only the library's refine loop (no torch-ops leg, no side metrics)")
     ap.add_argument("--adversarial", action="store_true", help="i.i.d. uniform disparity (worst-case gather)")
     args = ap.parse_args()
+    if args.miopen_find:
+        torch.backends.cudnn.benchmark = True
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
