@@ -80,6 +80,19 @@ def synthetic_inputs(cfg, device, seed):
     return f1, f2, coords
 
 
+def moving_coords(coords, iters, seed):
+    """One coordinate tensor per lookup: the GRU moves coords1 a little every iteration
+    (core/raft_stereo.py:120-123), so no two lookups of a pass read exactly the same windows.  x gets a
+    seeded U(-1, 1) px offset per pixel and lookup (y, the row index, stays); made before the timed region."""
+    g = torch.Generator(device=coords.device).manual_seed(seed + 4242)
+    out = []
+    for _ in range(iters):
+        c = coords.clone()
+        c[:, 0] += torch.rand(c[:, 0].shape, generator=g, device=coords.device) * 2 - 1
+        out.append(c)
+    return out
+
+
 def measured_traffic(workload, batch, kernel):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this workload
     (profiles/<round>/<workload>_b<batch>_pmc.json, written by tools/pmc_summarize.py): 2 x FETCH_SIZE +
@@ -118,6 +131,7 @@ class Step:
         import raft_stereo_amd as R
         self.R, self.cfg = R, cfg
         self.f1, self.f2, self.coords = synthetic_inputs(cfg, device, seed)
+        self.coords_list = moving_coords(self.coords, cfg["iters"], seed)
         self.train = cfg["train"]
         if self.train:
             self.f1.requires_grad_(True)
@@ -139,8 +153,8 @@ class Step:
         if record:
             self.ev[1].record()
         outs = []
-        for _ in range(cfg["iters"]):
-            out = blk(self.coords)
+        for k in range(cfg["iters"]):
+            out = blk(self.coords_list[k])
             if self.train:
                 outs.append(out)
         if record:
@@ -542,6 +556,32 @@ def refine_train_step(step, cfg, device, reps=2):
                 refine_train_peak_gib=round(peak_ours, 2), refine_train_peak_gib_torch_ops=round(peak_torch, 2))
 
 
+def hbm_resident_lookup(cfg, device, seed, batch=64, passes=3):
+    """The lookup's roofline once more at a batch whose touched pyramid lines and outputs no longer fit
+    the 256 MiB Infinity Cache (64 KITTI pairs: what one pass reads and writes is ~0.5 GB), beside the
+    per-GPU headline batch: build once, then `iters` lookups with moving coordinates, HIP events on
+    the current stream, average per launch over `passes` passes."""
+    big = dict(cfg, batch=batch)
+    st = Step(big, device, seed)
+    with torch.no_grad():
+        blk = st.cls(st.f1, st.f2, num_levels=LEVELS, radius=RADIUS)
+        for c in st.coords_list[:3]:
+            blk(c)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(passes):
+            for c in st.coords_list:
+                blk(c)
+        b.record()
+        b.synchronize()
+    us = a.elapsed_time(b) / (passes * len(st.coords_list)) * 1e3
+    alg = algorithmic_counts(big)["lookup_bytes"]
+    ach = alg / (us * 1e-6) / 1e9
+    return dict(batch=batch, bound="hbm", kernel="lookup_fwd_kernel", achieved=round(ach, 1), peak=HBM_PEAK_GBS,
+                unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), avg_launch_us=round(us, 2),
+                algorithmic_bytes_per_launch=int(alg), traffic=measured_traffic("kitti", batch, "lookup_fwd_kernel"))
+
+
 def hip_graph_step(step, n=50):
     """The same step (build/prepare + lookups) captured once in a HIP graph and replayed: what a
     caller that captures its GRU loop pays per pair batch once launch overhead is gone.  Reported
@@ -636,6 +676,7 @@ def main():
     step = Step(cfg, device, seed=1234 + rank)
     if args.adversarial:
         step.coords = torch.from_numpy(synthetic_coords(cfg["batch"], cfg["H"], cfg["W"], seed=7, adversarial=True)).to(device)
+        step.coords_list = moving_coords(step.coords, cfg["iters"], 7)
 
     def barrier():
         torch.cuda.synchronize()
@@ -705,6 +746,10 @@ def main():
         extra.update(refine_train_step(step, cfg, device))
     if not cfg["train"] and world == 1 and not args.loop_only:       # side metric; kept out of multi-rank runs (no capture beside RCCL)
         extra.update(hip_graph_step(step))
+    if args.workload == "kitti" and not args.batch and not args.dtype and rank == 0 and not args.loop_only:
+        # the same kernel with nothing left in the Infinity Cache between lookups (after the timed region)
+        extra["roofline_hbm_resident"] = hbm_resident_lookup(cfg, device, 1234 + rank)
+        extra["lookup_frac_hbm_resident"] = extra["roofline_hbm_resident"]["frac"]
 
     if not args.dtype and not args.adversarial:     # the committed profiles are of the stock workloads
         roof["traffic"] = measured_traffic(args.workload, cfg["batch"], roof["kernel"])
@@ -718,7 +763,9 @@ def main():
                                f"per GPU, {LEVELS} levels, radius {RADIUS}",
                    "per_gpu_batch": cfg["batch"], "global_batch": cfg["batch"] * world, "iters": cfg["iters"],
                    "partition": "image pairs per rank, no data-path collective",
-                   "coords": "adversarial" if args.adversarial else "piecewise-smooth"},
+                   "coords": ("adversarial (i.i.d. uniform disparity)" if args.adversarial else
+                              "piecewise-smooth disparity (SURVEY 8d)") +
+                             ", x moved by a seeded U(-1,1) px per pixel before every lookup"},
         "roofline": roof,
     }
     line.update(extra)

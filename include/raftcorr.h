@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define RC_VERSION 100          /* 0.1.0 */
+#define RC_VERSION 200          /* 0.2.0: forward pyramids keep the even levels only */
 #define RC_MAX_LEVELS 4
 #define RC_MAX_RADIUS 8
 #define RC_MAX_FUSED_LOOKUPS 32  /* lookups one rc_lookup_bwd_dense call can take */
@@ -70,40 +70,54 @@ enum {
 };
 
 /*
- * Private layout of the correlation pyramid ("group-skewed blocks"):
+ * Private layout of the correlation pyramid ("group-skewed blocks, even levels stored"):
  * the column of pixel (b,h,w1) at level i -- its width[i] correlations against w2 = 0.. --
  * is cut into groups of rb = 16 / element-size consecutive w2, one 16-byte block each.  Group
  * g = w2 / rb of that pixel is stored in block row
  *     sb = (g - ((w1 >> i) / rb) + nb - 32 / rb) mod nb,          nb = widthp[i] / rb,
  * and element (b,h,w1,w2) of level i lives at
  *     offset[i] + (((b*H + h) * nb + sb) * pitch + w1) * rb + w2 % rb.
- * Consequences: (1) the 2r+2 taps of a lookup are 2-3 whole blocks, and neighbouring pixels
+ * Consequences: (1) the taps of a lookup are a few whole blocks, and neighbouring pixels
  * with similar disparity read neighbouring blocks of the same block rows (16 bytes per lane,
  * long contiguous runs per wave); (2) the 4 consecutive w2 an MFMA lane owns after the build are
  * half (16-bit) or all (f32) of one block, so the build writes the pyramid straight from
  * registers in full 128-byte lines; (3) the wrap-around of a column sits at disparities of
- * about -32 level-i pixels.  Nothing outside this library and its Python wrapper may index the
- * pyramid.
+ * about -32 level-i pixels.
+ * A forward pyramid (rc_pyramid_layout) keeps only the EVEN levels in memory (stored[i] != 0):
+ * entry j of level i+1 is the mean of entries 2j, 2j+1 of level i (core/corr.py:124), and the
+ * 2r+2 entries of level i+1 a lookup needs lie over 4r+4 consecutive entries of level i that
+ * contain the lookup's own level-i window, so the lookup kernels read that one run and derive
+ * level i+1 in registers with the build's arithmetic (fp32 mean of the stored values, rounded to
+ * the storage type).  The pyramid is 1.25 x level 0 instead of 1.875 x, and a lookup touches
+ * two runs per pixel instead of four.  A gradient pyramid (rc_grad_pyramid_layout, always
+ * RC_F32) stores every level.  Nothing outside this library and its Python wrapper may index
+ * the pyramid.
  */
 typedef struct rc_layout {
   int64_t B, H, W1, W2;
-  int32_t L;                        /* levels stored (= levels ever read, corr.py:133-134) */
+  int32_t L;                        /* levels of the pyramid (= levels ever read, corr.py:133-134) */
   int32_t pitch;                    /* W1 rounded up to a multiple of 64 pixels */
   int32_t rb;                       /* w2 per 16-byte block: 8 (f16/bf16) or 4 (f32) */
   int32_t dtype;                    /* element type the layout was made for */
   int32_t width[RC_MAX_LEVELS];     /* W2 >> i */
   int32_t widthp[RC_MAX_LEVELS];    /* width rounded up to a multiple of 8 */
-  int64_t offset[RC_MAX_LEVELS];    /* element offset of level i */
+  int32_t stored[RC_MAX_LEVELS];    /* level i has memory (forward pyramids: even levels only) */
+  int32_t full;                     /* made by rc_grad_pyramid_layout: every level stored */
+  int32_t reserved;
+  int64_t offset[RC_MAX_LEVELS];    /* element offset of level i (0 when not stored) */
   int64_t total;                    /* elements in the whole pyramid */
 } rc_layout;
 
 int rc_version(void);
 const char* rc_last_error_string(void);
 
-/* Fills *out for a pyramid of `dtype` elements; RC_EINVAL if W2 >> (L-1) < 1 or any size is
- * non-positive.  A float gradient pyramid needs its own layout (dtype RC_F32). */
+/* Fills *out for a forward pyramid of `dtype` elements (even levels stored); RC_EINVAL if
+ * W2 >> (L-1) < 1 or any size is non-positive. */
 int rc_pyramid_layout(int64_t B, int64_t H, int64_t W1, int64_t W2, int L, int dtype,
                       rc_layout* out);
+/* The float gradient pyramid rc_lookup_bwd accumulates into and rc_build_bwd folds (every level
+ * stored, dtype RC_F32); also what rc_lookup_bwd_dense / rc_build_bwd_dense take for the geometry. */
+int rc_grad_pyramid_layout(int64_t B, int64_t H, int64_t W1, int64_t W2, int L, rc_layout* out);
 
 /*
  * Build all levels of the pyramid: C = f1^T f2 / sqrt(D) per image row, then the pairwise

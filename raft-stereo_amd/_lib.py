@@ -14,6 +14,7 @@ RC_CONVC1_MAX_RADIUS = 7
 RC_F32, RC_F16, RC_BF16 = 0, 1, 2
 RC_COORD_EXACT, RC_COORD_GRIDSAMPLE = 0, 1
 RC_WRAP_ROWS = 32
+RC_VERSION = 200
 
 LIB_NAME = "libraftcorr_hip.so"
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
@@ -25,6 +26,8 @@ class Layout(C.Structure):
                 ("L", C.c_int32), ("pitch", C.c_int32), ("rb", C.c_int32), ("dtype", C.c_int32),
                 ("width", C.c_int32 * RC_MAX_LEVELS),
                 ("widthp", C.c_int32 * RC_MAX_LEVELS),
+                ("stored", C.c_int32 * RC_MAX_LEVELS),
+                ("full", C.c_int32), ("reserved", C.c_int32),
                 ("offset", C.c_int64 * RC_MAX_LEVELS),
                 ("total", C.c_int64)]
 
@@ -48,6 +51,7 @@ SIGNATURES = {
     "rc_version": (_I, []),
     "rc_last_error_string": (C.c_char_p, []),
     "rc_pyramid_layout": (_I, [_L, _L, _L, _L, _I, _I, _LP]),
+    "rc_grad_pyramid_layout": (_I, [_L, _L, _L, _L, _I, _LP]),
     "rc_build_pyramid": (_I, [_P, _P, _P, _LP, _L, _I, _P]),
     "rc_build_pyramid_naive": (_I, [_P, _P, _P, _LP, _L, _I, _P]),
     "rc_lookup_fwd": (_I, [_P, _LP, _P, _I, _P, _I, _I, _P]),

@@ -230,7 +230,7 @@ class CorrBlock1DHip:
         self.layout = Layout()          # of the volume
         self.grad_layout = Layout()     # of the float gradient pyramid
         check(lib.rc_pyramid_layout(B, H, W1, W2, num_levels, self.vol_dtype, self.layout), "rc_pyramid_layout")
-        check(lib.rc_pyramid_layout(B, H, W1, W2, num_levels, _lib.RC_F32, self.grad_layout), "rc_pyramid_layout")
+        check(lib.rc_grad_pyramid_layout(B, H, W1, W2, num_levels, self.grad_layout), "rc_grad_pyramid_layout")
         self.volume = None
         self._pending = []              # (coords, grad_out) of lookups whose backward has run
         fmap1, fmap2 = fmap1.contiguous(), fmap2.contiguous()
@@ -334,9 +334,15 @@ class CorrBlock1DHip:
     # -- test / debug helper: the pyramid in the reference's dense layout
     def dense_level(self, i, volume=None, layout=None):
         """Level i as a dense [B,H,W1,W2>>i] tensor (un-skews the private layout with torch
-        indexing; for tests only)."""
+        indexing; for tests only).  A level the layout does not store is the pairwise mean of the
+        level below (fp32 mean of the stored values, rounded to the storage type) -- what the lookup
+        kernels derive in registers."""
         lay = layout or self.layout
         vol = self.volume if volume is None else volume
+        if not lay.stored[i]:
+            below = self.dense_level(i - 1, volume=vol, layout=lay)
+            n = lay.width[i]
+            return ((below[..., 0:2 * n:2].float() + below[..., 1:2 * n:2].float()) * 0.5).to(below.dtype)
         Wi, WiP, pitch, rb = lay.width[i], lay.widthp[i], lay.pitch, lay.rb
         nb = WiP // rb
         n = self.B * self.H * WiP * pitch
@@ -370,7 +376,7 @@ class AltCorrBlock1DHip:
         # the adjoint of the alt lookups is the adjoint of the reg lookups (same function of the
         # feature maps): the backward needs only the geometry of a pyramid, never its memory
         self.grad_layout = Layout()
-        check(lib.rc_pyramid_layout(B, H, W1, W2, num_levels, _lib.RC_F32, self.grad_layout), "rc_pyramid_layout")
+        check(lib.rc_grad_pyramid_layout(B, H, W1, W2, num_levels, self.grad_layout), "rc_grad_pyramid_layout")
         self.volume = None
         self._pending = []
         self._out_shape = (B, num_levels * (2 * radius + 1), H, W1)

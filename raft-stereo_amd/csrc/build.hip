@@ -223,31 +223,19 @@ __device__ __forceinline__ void epilogue16(const f4v (&acc)[4][2], float scale, 
     swap16(x[0][1], x[1][1]);
     om.store16(0, col_sw, ((n0 + 16 * rt) >> 3) + (g >> 1), x[0][0], x[0][1], x[1][0], x[1][1]);
   }
-  if (L < 2) return;
+  if (L < 3) return;  // level 1 is not stored (the lookup derives it from level 0); level 2 is its pairwise mean
   float p2[4][2];
 #pragma unroll
-  for (int ct = 0; ct < 2; ++ct) {
-    uint32_t q[4];
+  for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
-      q[rt] = q1[rt][ct];
-      p2[rt][ct] = 0.5f * (unpack_lo<VT>(q[rt]) + unpack_hi<VT>(q[rt]));
-    }
-    transpose_rows(q);  // lane row g: the level-1 block of row tile g
-    om.store16(1, cw + 16 * ct + li, (n0 >> 4) + g, q[0], q[1], q[2], q[3]);
-  }
-  if (L < 3) return;
+    for (int rt = 0; rt < 4; ++rt) p2[rt][ct] = 0.5f * (unpack_lo<VT>(q1[rt][ct]) + unpack_hi<VT>(q1[rt][ct]));
   uint32_t w[4];  // w[ct + 2 m] = level-2 values of row tiles 2m, 2m+1: block elements g and 4 + g
 #pragma unroll
   for (int j = 0; j < 4; ++j) w[j] = pack2<VT>(p2[2 * (j >> 1)][j & 1], p2[2 * (j >> 1) + 1][j & 1]);
   transpose_rows(w);  // lane row j: w[p] = elements (p, 4 + p) of the block of (column tile j & 1, m = j >> 1)
   const uint32_t d0 = __builtin_amdgcn_perm(w[1], w[0], 0x05040100u), d1 = __builtin_amdgcn_perm(w[3], w[2], 0x05040100u);
   const uint32_t d2 = __builtin_amdgcn_perm(w[1], w[0], 0x07060302u), d3 = __builtin_amdgcn_perm(w[3], w[2], 0x07060302u);
-  om.store16(2, col_sw, (n0 >> 5) + (g >> 1), d0, d1, d2, d3);
-  if (L < 4) return;
-  const float e0 = 0.5f * (unpack_lo<VT>(d0) + unpack_hi<VT>(d0)), e1 = 0.5f * (unpack_lo<VT>(d1) + unpack_hi<VT>(d1));
-  const float e2 = 0.5f * (unpack_lo<VT>(d2) + unpack_hi<VT>(d2)), e3 = 0.5f * (unpack_lo<VT>(d3) + unpack_hi<VT>(d3));
-  om.store8(3, col_sw, n0 >> 6, g >> 1, pack2<VT>(e0, e1), pack2<VT>(e2, e3));
+  om.store16(2, col_sw, (n0 >> 5) + (g >> 1), d0, d1, d2, d3);  // level 3 is derived from this one
 }
 
 // ---- epilogue, f32 pyramid: a 32 (w2) x 32 (w1) wave tile (two row tiles), n0 a multiple of 32.
@@ -270,28 +258,18 @@ __device__ __forceinline__ void epilogue32(const f4v& a00, const f4v& a01, const
       p1[rt][ct][0] = 0.5f * (v[0] + v[1]);
       p1[rt][ct][1] = 0.5f * (v[2] + v[3]);
     }
-  if (L < 2) return;
+  if (L < 3) return;  // levels 1 and 3 are not stored
   float p2[2][2];
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt) {
-    uint32_t a0 = __float_as_uint(p1[rt][0][0]), b0 = __float_as_uint(p1[rt][0][1]);
-    uint32_t a1 = __float_as_uint(p1[rt][1][0]), b1 = __float_as_uint(p1[rt][1][1]);
     p2[rt][0] = 0.5f * (p1[rt][0][0] + p1[rt][0][1]);
     p2[rt][1] = 0.5f * (p1[rt][1][0] + p1[rt][1][1]);
-    swap16(a0, a1);
-    swap16(b0, b1);
-    om.store16(1, col_sw, (((n0 >> 1) + 8 * rt) >> 2) + (g >> 1), a0, b0, a1, b1);
   }
-  if (L < 3) return;
   uint32_t r[4];  // r[ct + 2 rt]
 #pragma unroll
   for (int j = 0; j < 4; ++j) r[j] = __float_as_uint(p2[j >> 1][j & 1]);
   transpose_rows(r);  // lane row j: the level-2 block of (column tile j & 1, row tile j >> 1)
   om.store16(2, col_sw, (n0 >> 4) + (g >> 1), r[0], r[1], r[2], r[3]);
-  if (L < 4) return;
-  const float q0 = 0.5f * (__uint_as_float(r[0]) + __uint_as_float(r[1]));
-  const float q1 = 0.5f * (__uint_as_float(r[2]) + __uint_as_float(r[3]));
-  om.store8(3, col_sw, n0 >> 5, g >> 1, __float_as_uint(q0), __float_as_uint(q1));
 }
 
 template <typename T, typename VT, int FAST>
@@ -450,6 +428,8 @@ __global__ void naive_corr_kernel(const T* __restrict__ f1, const T* __restrict_
   vol[rc_cell<RB>(lay, 0, bh, w1, w2)] = rc_from_float<VT>(acc * scale);
 }
 
+// stored level `level` (even, >= 2) from stored level `level - 2`: two pooling steps, each the fp32 mean of
+// two values of the storage type, rounded to it (avg_pool2d on a 16-bit volume, core/corr.py:42)
 template <typename VT>
 __global__ void naive_pool_kernel(VT* __restrict__ vol, rc_dev_layout lay, int level, int64_t total) {
   constexpr int RB = 16 / (int)sizeof(VT);
@@ -460,9 +440,14 @@ __global__ void naive_pool_kernel(VT* __restrict__ vol, rc_dev_layout lay, int l
   const int64_t t = idx / W1;
   const int w2 = (int)(t % Wi);
   const int64_t bh = t / Wi;
-  const float a = rc_to_float(vol[rc_cell<RB>(lay, level - 1, bh, w1, 2 * w2)]);
-  const float bb = rc_to_float(vol[rc_cell<RB>(lay, level - 1, bh, w1, 2 * w2 + 1)]);
-  vol[rc_cell<RB>(lay, level, bh, w1, w2)] = rc_from_float<VT>(0.5f * (a + bb));
+  float m[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const float a = rc_to_float(vol[rc_cell<RB>(lay, level - 2, bh, w1, 4 * w2 + 2 * e)]);
+    const float bb = rc_to_float(vol[rc_cell<RB>(lay, level - 2, bh, w1, 4 * w2 + 2 * e + 1)]);
+    m[e] = rc_round_as<VT>(0.5f * (a + bb));
+  }
+  vol[rc_cell<RB>(lay, level, bh, w1, w2)] = rc_from_float<VT>(0.5f * (m[0] + m[1]));
 }
 
 template <typename T, typename VT>
@@ -473,7 +458,7 @@ int launch_naive(const void* f1, const void* f2, void* vol, const rc_layout* lay
   hipLaunchKernelGGL((naive_corr_kernel<T, VT>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                      (const T*)f1, (const T*)f2, (VT*)vol, d, D, scale, total);
   int rc = rc_check_launch("rc_build_pyramid(naive corr)");
-  for (int i = 1; i < lay->L && !rc; ++i) {
+  for (int i = 2; i < lay->L && !rc; i += 2) {
     total = lay->B * lay->H * (int64_t)lay->width[i] * lay->W1;
     hipLaunchKernelGGL((naive_pool_kernel<VT>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                        (VT*)vol, d, i, total);
@@ -548,6 +533,7 @@ static int build_dispatch(const void* f1, const void* f2, void* vol, const rc_la
   if (rc) return rc;
   RC_REQUIRE(D >= 1 && D < (1 << 20), RC_EINVAL, "bad feature depth D=%lld", (long long)D);
   RC_REQUIRE((uintptr_t)vol % 16 == 0, RC_EINVAL, "pyramid pointer must be 16-byte aligned");
+  RC_REQUIRE(!lay->full, RC_EINVAL, "rc_build_pyramid takes a forward pyramid (rc_pyramid_layout)");
   const float scale = (float)(1.0 / sqrt((double)D));
   hipStream_t st = (hipStream_t)stream;
   const bool naive = force_naive || D > KMAX;

@@ -25,8 +25,7 @@ extern "C" int rc_version(void) { return RC_VERSION; }
 
 extern "C" const char* rc_last_error_string(void) { return g_err; }
 
-extern "C" int rc_pyramid_layout(int64_t B, int64_t H, int64_t W1, int64_t W2, int L, int dtype,
-                                 rc_layout* out) {
+static int make_layout(int64_t B, int64_t H, int64_t W1, int64_t W2, int L, int dtype, bool full, rc_layout* out) {
   RC_REQUIRE(out != nullptr, RC_EINVAL, "rc_pyramid_layout: null output");
   RC_REQUIRE(B > 0 && H > 0 && W1 > 0 && W2 > 0, RC_EINVAL,
              "rc_pyramid_layout: non-positive size B=%lld H=%lld W1=%lld W2=%lld", (long long)B, (long long)H,
@@ -45,10 +44,13 @@ extern "C" int rc_pyramid_layout(int64_t B, int64_t H, int64_t W1, int64_t W2, i
   out->pitch = (int32_t)((W1 + 63) / 64 * 64);
   out->rb = dtype == RC_F32 ? 4 : 8;
   out->dtype = dtype;
+  out->full = full ? 1 : 0;
   int64_t off = 0;
   for (int i = 0; i < L; ++i) {
     out->width[i] = (int32_t)(W2 >> i);
     out->widthp[i] = (out->width[i] + 7) / 8 * 8;
+    out->stored[i] = (full || (i & 1) == 0) ? 1 : 0;  // odd levels of a forward pyramid are derived in registers
+    if (!out->stored[i]) continue;
     out->offset[i] = off;
     off += B * H * (int64_t)out->widthp[i] * out->pitch;
   }
@@ -56,10 +58,20 @@ extern "C" int rc_pyramid_layout(int64_t B, int64_t H, int64_t W1, int64_t W2, i
   return RC_OK;
 }
 
+extern "C" int rc_pyramid_layout(int64_t B, int64_t H, int64_t W1, int64_t W2, int L, int dtype,
+                                 rc_layout* out) {
+  return make_layout(B, H, W1, W2, L, dtype, false, out);
+}
+
+extern "C" int rc_grad_pyramid_layout(int64_t B, int64_t H, int64_t W1, int64_t W2, int L, rc_layout* out) {
+  return make_layout(B, H, W1, W2, L, RC_F32, true, out);
+}
+
 int rc_validate_layout(const rc_layout* lay) {
   rc_layout ref;
-  int rc = rc_pyramid_layout(lay->B, lay->H, lay->W1, lay->W2, lay->L, lay->dtype, &ref);
+  int rc = make_layout(lay->B, lay->H, lay->W1, lay->W2, lay->L, lay->dtype, lay->full != 0, &ref);
   if (rc) return rc;
-  RC_REQUIRE(memcmp(&ref, lay, sizeof(ref)) == 0, RC_EINVAL, "rc_layout was not produced by rc_pyramid_layout");
+  RC_REQUIRE(memcmp(&ref, lay, sizeof(ref)) == 0, RC_EINVAL,
+             "rc_layout was not produced by rc_pyramid_layout / rc_grad_pyramid_layout");
   return RC_OK;
 }

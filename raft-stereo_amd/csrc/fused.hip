@@ -5,15 +5,17 @@
 // (`cor = F.relu(self.convc1(corr))`) of the reference: the L*(2r+1)-channel fp32 tensor between
 // the two (144 B written + 144 B read back per pixel and iteration) never exists.
 //
-// A wave owns 64 consecutive pixels of one image row and handles them 16 at a time.  In a pass,
-// lane (g, li) = (lane / 16, lane % 16) produces the 2r+1 taps of pixel li at pyramid LEVEL g,
-// with the same 16-byte block loads and in-register window decode as the plain lookup.  That is
-// exactly the B-operand layout of the MFMA (column = pixel, K slot = 16 g + tap), so the taps go
-// straight from the interpolation into  C[out channel][pixel] += Wp[out channel][K] * taps[K][pixel],
-// K = 4 levels x 16 tap slots (unused slots carry zero weights).  Weights come pre-arranged in
-// fragment order (rc_convc1_pack); the accumulators start from the bias.  After the four passes a
-// 4x4 transpose over the lane rows (v_permlane16/32_swap) leaves lane = pixel, so every output
-// channel plane is written in one contiguous run per wave.
+// A wave owns 64 consecutive pixels of one image row.  Gather: lane = pixel, exactly the plain lookup
+// (two runs of 16-byte blocks per pixel, levels 1 and 3 derived in registers; every load instruction
+// of the wave reads long contiguous runs).  The taps are rounded to the pyramid's type and packed,
+// K slot = 16 level + tap.  A 4x4 transpose over the lane rows (v_permlane16/32_swap) per packed
+// dword then gives lane (g, li) the slots of LEVEL g of pixel 16 s + li in register s: the
+// B-operand layout of the MFMA (column = pixel, K = 8 (lane / 16) + j within a 32-slot step), so
+//     C[out channel][pixel] += Wp[out channel][K] * taps[K][pixel],   K = 4 levels x 16 tap slots
+// (unused slots carry zero weights and zero taps) runs once per 16 pixels.  Weights come
+// pre-arranged in fragment order (rc_convc1_pack); the accumulators start from the bias.  A second
+// 4x4 transpose leaves lane = pixel again, so every output channel plane is written in one
+// contiguous run per wave.
 //   16-bit pyramid: taps rounded to the pyramid's type, v_mfma_f32_16x16x32 (f32 accumulate),
 //                   output in that type (what autocast makes of convc1);
 //   f32 pyramid:    v_mfma_f32_16x16x4_f32, f32 output.
@@ -89,6 +91,24 @@ __global__ __launch_bounds__(256) void convc1_pack_kernel(const float* __restric
   packed[idx] = rc_from_float<T>(v);
 }
 
+__device__ __forceinline__ void swap16u(uint32_t& x, uint32_t& y) {
+  const auto r = __builtin_amdgcn_permlane16_swap(x, y, false, false);
+  x = r[0];
+  y = r[1];
+}
+__device__ __forceinline__ void swap32u(uint32_t& x, uint32_t& y) {
+  const auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+  x = r[0];
+  y = r[1];
+}
+// 4x4 transpose over lane rows: afterwards lane row g holds in r[p] what lane row p held in r[g]
+__device__ __forceinline__ void transpose_rows(uint32_t (&r)[4]) {
+  swap16u(r[0], r[1]);
+  swap16u(r[2], r[3]);
+  swap32u(r[0], r[2]);
+  swap32u(r[1], r[3]);
+}
+
 template <typename VT, int R, int MODE>
 __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __restrict__ vol, rc_dev_layout lay,
                                                                    const float* __restrict__ coords,
@@ -98,9 +118,10 @@ __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __r
                                                                    VT* __restrict__ out, int chunks_per_row,
                                                                    int n_items, int relu) {
   constexpr bool IS16 = sizeof(VT) == 2;
-  constexpr int RB = vt_info<VT>::RB, LG = vt_info<VT>::LG;
-  using WI = win_info<RB, R, MODE>;
-  constexpr int NT = WI::NT, EXT = WI::EXT, NW = WI::NW, NBLK = WI::NBLK, ND = WI::ND;
+  using PF = pair_fetch<VT, R, MODE>;
+  using SF = single_fetch<VT, R, MODE>;
+  constexpr int NT = 2 * R + 1, NW = PF::PI::NW;
+  constexpr int NDW = (NT + 1) / 2;  // packed dwords per level (16-bit)
   static_assert(NT <= FC_SLOTS, "a level's taps must fit its slots");
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -110,17 +131,53 @@ __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __r
   const int c0 = (item - bh * chunks_per_row) * 64;
   const int b = bh / lay.H, h = bh - b * lay.H;
   const int64_t HW = (int64_t)lay.H * lay.W1;
-  const int g = lane >> 4, li = lane & 15;
+  const int g = lane >> 4;
   const uint32_t blk_bytes = (uint32_t)lay.pitch * 16u;
+  const int L = lay.L;
+  const int w1g = min(c0 + lane, lay.W1 - 1);  // pixels past the row end repeat the last one (never stored)
 
-  // the lane's level
-  const bool has_level = g < lay.L;
-  const int i = has_level ? g : 0;
-  const int Wi = pick4(lay.width, i), nb = pick4(lay.widthp, i) >> LG, rbias = pick4(lay.bias, i);
-  const float inv = 1.0f / (float)(1 << i);
-  const char* lvl = reinterpret_cast<const char*>(vol) + pick4(lay.offset, i) * (int64_t)sizeof(VT) +
-                    (int64_t)bh * nb * blk_bytes;
-  const bool tiny = nb < NBLK;
+  // ---- phase 1: the plain lookup's gather, lane = pixel: taps of every level in registers
+  const float x = (coords + uniform(((int64_t)b * coords_channels) * HW + (int64_t)h * lay.W1))[w1g];
+  float tap[RC_MAX_LEVELS][NT];
+#pragma unroll
+  for (int i = 0; i < RC_MAX_LEVELS; ++i)
+#pragma unroll
+    for (int k = 0; k < NT; ++k) tap[i][k] = 0.f;
+  if (L == 4) {  // both runs in flight together
+    PF p0, p2;
+    p0.issue(vol, lay, 0, x, w1g, bh, blk_bytes);
+    p2.issue(vol, lay, 2, x, w1g, bh, blk_bytes);
+    float lo[NW], hi[NW];
+    p0.windows(lay, 0, lo, hi);
+    interp_taps<R, MODE, NW>(lo, p0.s_lo, lay.width[0], p0.x_lo, p0.f_lo, tap[0]);
+    interp_taps<R, MODE, NW>(hi, p0.s_hi, lay.width[1], p0.x_hi, p0.f_hi, tap[1]);
+    p2.windows(lay, 2, lo, hi);
+    interp_taps<R, MODE, NW>(lo, p2.s_lo, lay.width[2], p2.x_lo, p2.f_lo, tap[2]);
+    interp_taps<R, MODE, NW>(hi, p2.s_hi, lay.width[3], p2.x_hi, p2.f_hi, tap[3]);
+  } else {
+    if (L >= 2) {
+      PF pf;
+      pf.issue(vol, lay, 0, x, w1g, bh, blk_bytes);
+      float lo[NW], hi[NW];
+      pf.windows(lay, 0, lo, hi);
+      interp_taps<R, MODE, NW>(lo, pf.s_lo, lay.width[0], pf.x_lo, pf.f_lo, tap[0]);
+      interp_taps<R, MODE, NW>(hi, pf.s_hi, lay.width[1], pf.x_hi, pf.f_hi, tap[1]);
+    }
+    if (L == 1) {
+      SF sf;
+      sf.issue(vol, lay, 0, x, w1g, bh, blk_bytes);
+      float v[NW];
+      sf.window(lay, 0, v);
+      interp_taps<R, MODE, NW>(v, sf.pos.wbase, lay.width[0], sf.xi, sf.frac, tap[0]);
+    }
+    if (L == 3) {
+      SF sf;
+      sf.issue(vol, lay, 2, x, w1g, bh, blk_bytes);
+      float v[NW];
+      sf.window(lay, 2, v);
+      interp_taps<R, MODE, NW>(v, sf.pos.wbase, lay.width[2], sf.xi, sf.frac, tap[2]);
+    }
+  }
 
   // weights (A operand: row = out channel 16 t + li, K slots of level g) and bias (C rows 4 g + r)
   uint4 wa16[4][2];
@@ -140,79 +197,45 @@ __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __r
     for (int s = 0; s < 4; ++s) acc[s][t] = bv;
   }
 
-  // ---- phase 1: window addresses and block loads of the four passes
-  uint32_t d[4][ND];
-  win_pos pos[4];
-  float xi_[4], frac[4];
-  const float* crow = coords + uniform(((int64_t)b * coords_channels) * HW + (int64_t)h * lay.W1);
+  // ---- phase 2: lane rows <-> levels, then the 1x1 convolution on the matrix cores
+  if constexpr (IS16) {
+    uint32_t bq[4][8];  // [pass s][dword of the level's 16 slots] of lane (g, li): level g of pixel 16 s + li
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const int w1 = min(c0 + 16 * s + li, lay.W1 - 1);
-    const float xi = crow[w1] * inv;
-    const float xf = floorf(xi);
-    xi_[s] = xi;
-    frac[s] = xi - xf;
-    pos[s] = locate_window<RB, LG, NW>(rc_safe_int(xf) - R - EXT, w1, i, Wi, nb, rbias);
+    for (int j = 0; j < 8; ++j) {
+      if (j < NDW) {
+        uint32_t r[4];
 #pragma unroll
-    for (int k = 0; k < NBLK; ++k) {
-      const uint32_t sb = row_step(pos[s].sb0, (uint32_t)min(k, pos[s].nbk), (uint32_t)nb, tiny);
-      const uint4 q = *reinterpret_cast<const uint4*>(lvl + (__umul24(sb, blk_bytes) + (uint32_t)w1 * 16u));
-      d[s][4 * k + 0] = q.x;
-      d[s][4 * k + 1] = q.y;
-      d[s][4 * k + 2] = q.z;
-      d[s][4 * k + 3] = q.w;
-    }
-  }
-
-  // ---- phase 2: taps of (pixel, level), then the 1x1 convolution on the matrix cores
+        for (int i = 0; i < 4; ++i) r[i] = pack2<VT>(tap[i][2 * j], 2 * j + 1 < NT ? tap[i][2 * j + 1] : 0.f);
+        transpose_rows(r);
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const bool live = has_level && (c0 + 16 * s + li < lay.W1);
-    float v[NW];
-    decode_window<VT, NW, ND>(d[s], pos[s].o, v);
-    if (__any(pos[s].edge)) {  // interior waves skip the zero padding
+        for (int s = 0; s < 4; ++s) bq[s][j] = r[s];
+      } else {
 #pragma unroll
-      for (int m = 0; m < NW; ++m) v[m] = ((unsigned)(pos[s].wbase + m) < (unsigned)Wi) ? v[m] : 0.f;
-    }
-    const float keep = live ? 1.0f : 0.f;  // lanes without a level or past the row end contribute zero taps
-
-    float tap[FC_SLOTS];
-#pragma unroll
-    for (int k = NT; k < FC_SLOTS; ++k) tap[k] = 0.f;
-    if constexpr (MODE == RC_COORD_EXACT) {
-      const float a = frac[s] * keep, bw = keep - a;
-#pragma unroll
-      for (int k = 0; k < NT; ++k) tap[k] = v[k] * bw + v[k + 1] * a;
-    } else {
-      const float wm1 = (float)(Wi - 1);
-#pragma unroll
-      for (int k = 0; k < NT; ++k) {
-        int i0k;
-        float w0, w1w;
-        rc_gridsample_coords(xi_[s], k - R, wm1, &i0k, &w0, &w1w);
-        const int dlt = i0k - (pos[s].wbase + EXT + k);  // -1, 0 or +1
-        const float va = dlt < 0 ? v[k] : (dlt > 0 ? v[k + 2] : v[k + 1]);
-        const float vb = dlt < 0 ? v[k + 1] : (dlt > 0 ? v[k + 3] : v[k + 2]);
-        tap[k] = (va * w0 + vb * w1w) * keep;
+        for (int s = 0; s < 4; ++s) bq[s][j] = 0u;
       }
     }
-
-    if constexpr (IS16) {
-      const uint4 b0 = make_uint4(pack2<VT>(tap[0], tap[1]), pack2<VT>(tap[2], tap[3]), pack2<VT>(tap[4], tap[5]),
-                                  pack2<VT>(tap[6], tap[7]));
-      const uint4 b1 = make_uint4(pack2<VT>(tap[8], tap[9]), pack2<VT>(tap[10], tap[11]),
-                                  pack2<VT>(tap[12], tap[13]), pack2<VT>(tap[14], tap[15]));
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const uint4 b0 = make_uint4(bq[s][0], bq[s][1], bq[s][2], bq[s][3]);
+      const uint4 b1 = make_uint4(bq[s][4], bq[s][5], bq[s][6], bq[s][7]);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         acc[s][t] = mfma16<VT>(wa16[t][0], b0, acc[s][t]);
         if (NT > 8) acc[s][t] = mfma16<VT>(wa16[t][1], b1, acc[s][t]);
       }
-    } else {
+    }
+  } else {
 #pragma unroll
-      for (int e = 0; e < NT; ++e)
+    for (int e = 0; e < NT; ++e) {
+      uint32_t r[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) r[i] = __float_as_uint(tap[i][e]);
+      transpose_rows(r);  // r[s] of lane (g, li): tap e of level g of pixel 16 s + li
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int t = 0; t < 4; ++t)
-          acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa32[t][e], tap[e], acc[s][t], 0, 0, 0);
+          acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa32[t][e], __uint_as_float(r[s]), acc[s][t], 0, 0, 0);
     }
   }
 
@@ -271,11 +294,11 @@ int launch_fused(const void* vol, rc_dev_layout d, const float* coords, int cc, 
   const int n_items = (int)((int64_t)d.B * d.H * chunks);
   const int blocks = (n_items + (FC_THREADS / 64) - 1) / (FC_THREADS / 64);
   if (mode == RC_COORD_EXACT) {
-    set_row_bias(d, vt_info<VT>::RB, win_info<vt_info<VT>::RB, R, RC_COORD_EXACT>::NW);
+    set_row_bias(d, vt_info<VT>::RB, pair_info<vt_info<VT>::RB, R, RC_COORD_EXACT>::NW2);
     hipLaunchKernelGGL((lookup_convc1_kernel<VT, R, RC_COORD_EXACT>), dim3(blocks), dim3(FC_THREADS), 0, st,
                        (const VT*)vol, d, coords, cc, (const VT*)wpack, bias, (VT*)out, chunks, n_items, relu);
   } else {
-    set_row_bias(d, vt_info<VT>::RB, win_info<vt_info<VT>::RB, R, RC_COORD_GRIDSAMPLE>::NW);
+    set_row_bias(d, vt_info<VT>::RB, pair_info<vt_info<VT>::RB, R, RC_COORD_GRIDSAMPLE>::NW2);
     hipLaunchKernelGGL((lookup_convc1_kernel<VT, R, RC_COORD_GRIDSAMPLE>), dim3(blocks), dim3(FC_THREADS), 0, st,
                        (const VT*)vol, d, coords, cc, (const VT*)wpack, bias, (VT*)out, chunks, n_items, relu);
   }
@@ -336,6 +359,7 @@ extern "C" int rc_lookup_convc1_fwd(const void* vol, const rc_layout* lay, const
              radius, RC_CONVC1_MAX_RADIUS);
   int rc = check_common(lay, vol, coords, out, coords_channels, radius, coord_mode);
   if (rc) return rc;
+  RC_REQUIRE(!lay->full, RC_EINVAL, "rc_lookup_convc1_fwd takes a forward pyramid (rc_pyramid_layout)");
   RC_REQUIRE((uintptr_t)packed_weight % 16 == 0 && (uintptr_t)bias % 16 == 0, RC_EINVAL,
              "packed weights and bias must be 16-byte aligned");
   const rc_dev_layout d = rc_to_dev(lay);

@@ -27,20 +27,27 @@ struct lk_update {
   float* flow_out;     // [B,2,H,W1]
 };
 
-// LV > 0 is a compile-time level count: the 16-byte loads of all levels are issued back to back
-// (no branch in between: lanes that do not need a block re-read one they do need), then decoded,
-// interpolated and stored.  LV == 0 takes the level count from the layout and handles one level
-// at a time.
-template <typename VT, int R, int MODE, int LV>
+// Stores the 2r+1 taps of one level: one 256-byte run per channel plane and wave
+template <int NT>
+__device__ __forceinline__ void store_taps(float* __restrict__ out, int64_t plane0, int64_t HW, int lane,
+                                           const float (&tap)[NT]) {
+#pragma unroll
+  for (int k = 0; k < NT; ++k) (out + uniform(plane0 + k * HW))[lane] = tap[k];
+}
+
+// A forward pyramid keeps its even levels; levels (i, i+1) are served by one run of level i (pair_fetch in
+// window.h).  ALL4 (the model's configuration, 4 levels): the 16-byte loads of both runs are issued back to
+// back, then decoded, interpolated and stored.  Otherwise one pair (or the odd last level) at a time.
+template <typename VT, int R, int MODE, bool ALL4>
 __global__ __launch_bounds__(LK_THREADS) void lookup_fwd_kernel(const VT* __restrict__ vol,
                                                                 rc_dev_layout lay,
                                                                 const float* __restrict__ coords,
                                                                 int coords_channels,
                                                                 float* __restrict__ out,
                                                                 int chunks_per_row, int n_items, lk_update upd) {
-  constexpr int RB = vt_info<VT>::RB, LG = vt_info<VT>::LG;
-  using WI = win_info<RB, R, MODE>;
-  constexpr int NT = WI::NT, EXT = WI::EXT, NW = WI::NW, NBLK = WI::NBLK, ND = WI::ND;
+  using PF = pair_fetch<VT, R, MODE>;
+  using SF = single_fetch<VT, R, MODE>;
+  constexpr int NT = 2 * R + 1, NW = PF::PI::NW;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int item = blockIdx.x * (LK_THREADS / 64) + wave;  // (row, 64-pixel chunk), wave-uniform
@@ -51,8 +58,7 @@ __global__ __launch_bounds__(LK_THREADS) void lookup_fwd_kernel(const VT* __rest
   if (w1 >= lay.W1) return;
   const int b = bh / lay.H, h = bh - b * lay.H;
   const int64_t HW = (int64_t)lay.H * lay.W1;
-  constexpr int LB = LV ? LV : 1;  // levels in flight together
-  const int L = LV ? LV : lay.L;
+  const int L = ALL4 ? 4 : lay.L;
   const uint32_t blk_bytes = (uint32_t)lay.pitch * 16u;  // distance between block rows of a pixel
 
   float x = (coords + uniform(((int64_t)b * coords_channels) * HW + (int64_t)h * lay.W1 + c0))[lane];
@@ -71,78 +77,38 @@ __global__ __launch_bounds__(LK_THREADS) void lookup_fwd_kernel(const VT* __rest
   }
   const int64_t out_u = ((int64_t)b * L * NT) * HW + (int64_t)h * lay.W1 + c0;  // wave-uniform
 
-  for (int i0 = 0; i0 < L; i0 += LB) {
-    uint32_t d[LB][ND];
-    win_pos pos[LB];
-    float frac[LB];
+  auto finish_pair = [&](PF& pf, int i) {
+    float lo[NW], hi[NW], tap[NT];
+    pf.windows(lay, i, lo, hi);
+    interp_taps<R, MODE, NW>(lo, pf.s_lo, lay.width[i], pf.x_lo, pf.f_lo, tap);
+    store_taps<NT>(out, out_u + (int64_t)i * NT * HW, HW, lane, tap);
+    interp_taps<R, MODE, NW>(hi, pf.s_hi, lay.width[i + 1], pf.x_hi, pf.f_hi, tap);
+    store_taps<NT>(out, out_u + (int64_t)(i + 1) * NT * HW, HW, lane, tap);
+  };
 
-    // ---- phase 1: addresses and loads of LB levels
+  if constexpr (ALL4) {
+    PF p0, p2;
+    p0.issue(vol, lay, 0, x, w1, bh, blk_bytes);
+    p2.issue(vol, lay, 2, x, w1, bh, blk_bytes);
+    finish_pair(p0, 0);
+    finish_pair(p2, 2);
+  } else {
 #pragma unroll
-    for (int j = 0; j < LB; ++j) {
-      const int i = i0 + j;
-      const int Wi = lay.width[i], nb = lay.widthp[i] >> LG;
-      const float xi = x * (1.0f / (float)(1 << i));
-      const float xf = floorf(xi);
-      frac[j] = xi - xf;
-      pos[j] = locate_window<RB, LG, NW>(rc_safe_int(xf) - R - EXT, w1, i, Wi, nb, lay.bias[i]);
-      const char* lvl = reinterpret_cast<const char*>(vol) +
-                        uniform(lay.offset[i] * (int64_t)sizeof(VT) + (int64_t)bh * nb * blk_bytes);
-      const bool tiny = nb < NBLK;
-#pragma unroll
-      for (int k = 0; k < NBLK; ++k) {
-        const uint32_t sb = row_step(pos[j].sb0, (uint32_t)min(k, pos[j].nbk), (uint32_t)nb, tiny);
-        const uint4 q = *reinterpret_cast<const uint4*>(lvl + (__umul24(sb, blk_bytes) + (uint32_t)w1 * 16u));
-        d[j][4 * k + 0] = q.x;
-        d[j][4 * k + 1] = q.y;
-        d[j][4 * k + 2] = q.z;
-        d[j][4 * k + 3] = q.w;
+    for (int i = 0; i + 1 < RC_MAX_LEVELS; i += 2) {
+      if (i + 1 < L) {  // wave-uniform
+        PF pf;
+        pf.issue(vol, lay, i, x, w1, bh, blk_bytes);
+        finish_pair(pf, i);
       }
     }
-
-    // ---- phase 2: decode, interpolate, store
-#pragma unroll
-    for (int j = 0; j < LB; ++j) {
-      const int i = i0 + j;
-      const int Wi = lay.width[i];
-      const int64_t op = out_u + (int64_t)i * NT * HW;  // wave-uniform plane base
-      float v[NW];
-      decode_window<VT, NW, ND>(d[j], pos[j].o, v);
-      if (__any(pos[j].edge)) {  // interior waves skip the zero padding
-#pragma unroll
-        for (int m = 0; m < NW; ++m) v[m] = ((unsigned)(pos[j].wbase + m) < (unsigned)Wi) ? v[m] : 0.f;
-      }
-
-      if constexpr (MODE == RC_COORD_EXACT) {
-        const float a = frac[j], bw = 1.0f - a;
-#pragma unroll
-        for (int k = 0; k < NT; ++k) (out + uniform(op + k * HW))[lane] = v[k] * bw + v[k + 1] * a;
-      } else {
-        const float xi = x * (1.0f / (float)(1 << i));
-        const float wm1 = (float)(Wi - 1);
-        int dlt[NT];  // where grid_sample's floor landed relative to tap k: -1, 0 or +1
-        float w0[NT], w1w[NT];
-        bool odd = false;
-#pragma unroll
-        for (int k = 0; k < NT; ++k) {
-          int i0k;
-          rc_gridsample_coords(xi, k - R, wm1, &i0k, &w0[k], &w1w[k]);
-          dlt[k] = i0k - (pos[j].wbase + EXT + k);
-          odd |= (dlt[k] != 0);
-        }
-        if (__builtin_expect(__any(odd), 0)) {
-          // the fp32 round trip moved some tap across an integer: take it from the widened window
-#pragma unroll
-          for (int k = 0; k < NT; ++k) {
-            const float va = dlt[k] < 0 ? v[k] : (dlt[k] > 0 ? v[k + 2] : v[k + 1]);
-            const float vb = dlt[k] < 0 ? v[k + 1] : (dlt[k] > 0 ? v[k + 3] : v[k + 2]);
-            (out + uniform(op + k * HW))[lane] = va * w0[k] + vb * w1w[k];
-          }
-        } else {
-#pragma unroll
-          for (int k = 0; k < NT; ++k)
-            (out + uniform(op + k * HW))[lane] = v[k + EXT] * w0[k] + v[k + EXT + 1] * w1w[k];
-        }
-      }
+    if (L & 1) {  // the last level stands alone
+      const int i = L - 1;
+      SF sf;
+      sf.issue(vol, lay, i, x, w1, bh, blk_bytes);
+      float v[NW], tap[NT];
+      sf.window(lay, i, v);
+      interp_taps<R, MODE, NW>(v, sf.pos.wbase, lay.width[i], sf.xi, sf.frac, tap);
+      store_taps<NT>(out, out_u + (int64_t)i * NT * HW, HW, lane, tap);
     }
   }
 }
@@ -543,16 +509,16 @@ int dispatch_adjoint_dense(const adj_lists& lists, const adj_dims& d, void* dC, 
 template <typename VT, int R, int MODE>
 int launch_fwd_mode(const void* vol, rc_dev_layout d, const float* coords, int cc, float* out, hipStream_t st,
                     const lk_update& upd) {
-  using WI = win_info<vt_info<VT>::RB, R, MODE>;
-  set_row_bias(d, vt_info<VT>::RB, WI::NW);
+  using PI = pair_info<vt_info<VT>::RB, R, MODE>;
+  set_row_bias(d, vt_info<VT>::RB, PI::NW2);
   const int chunks = (d.W1 + 63) / 64;
   const int n_items = (int)((int64_t)d.B * d.H * chunks);
   const int blocks = (n_items + (LK_THREADS / 64) - 1) / (LK_THREADS / 64);
   if (R == 4 && d.L == 4)  // the model's configuration: all levels' loads in flight together
-    hipLaunchKernelGGL((lookup_fwd_kernel<VT, R, MODE, (R == 4 ? 4 : 0)>), dim3(blocks), dim3(LK_THREADS), 0, st,
+    hipLaunchKernelGGL((lookup_fwd_kernel<VT, R, MODE, R == 4>), dim3(blocks), dim3(LK_THREADS), 0, st,
                        (const VT*)vol, d, coords, cc, out, chunks, n_items, upd);
   else
-    hipLaunchKernelGGL((lookup_fwd_kernel<VT, R, MODE, 0>), dim3(blocks), dim3(LK_THREADS), 0, st, (const VT*)vol,
+    hipLaunchKernelGGL((lookup_fwd_kernel<VT, R, MODE, false>), dim3(blocks), dim3(LK_THREADS), 0, st, (const VT*)vol,
                        d, coords, cc, out, chunks, n_items, upd);
   return rc_check_launch("rc_lookup_fwd");
 }
@@ -606,6 +572,7 @@ static int lookup_fwd_any(const void* vol, const rc_layout* lay, const float* co
                           float* out, int radius, int coord_mode, void* stream, const lk_update& upd) {
   int rc = check_common(lay, vol, coords, out, coords_channels, radius, coord_mode);
   if (rc) return rc;
+  RC_REQUIRE(!lay->full, RC_EINVAL, "rc_lookup_fwd takes a forward pyramid (rc_pyramid_layout)");
   const rc_dev_layout d = rc_to_dev(lay);
   hipStream_t st = (hipStream_t)stream;
   switch (lay->dtype) {
@@ -638,7 +605,8 @@ extern "C" int rc_lookup_bwd(const float* coords, int coords_channels, const flo
                              void* stream) {
   int rc = check_common(glay, grad_vol, coords, grad_out, coords_channels, radius, coord_mode);
   if (rc) return rc;
-  RC_REQUIRE(glay->dtype == RC_F32, RC_EINVAL, "the gradient pyramid must use an RC_F32 layout");
+  RC_REQUIRE(glay->dtype == RC_F32 && glay->full, RC_EINVAL,
+             "the gradient pyramid must use an rc_grad_pyramid_layout");
   const rc_dev_layout d = rc_to_dev(glay);
   hipStream_t st = (hipStream_t)stream;
   switch (radius) {

@@ -109,6 +109,197 @@ __device__ __forceinline__ void decode_window(uint32_t (&d)[ND], int o, float (&
   }
 }
 
+// ---- merged windows of a forward pyramid: level i (stored) read together with level i + 1 (derived).
+// Entry j of level i+1 is the mean of entries 2j, 2j+1 of level i, so the NW entries of level i+1 starting
+// at s_hi lie over the 2 NW entries of level i starting at 2 s_hi (an EVEN element: no sub-dword shift for
+// 16-bit types), and because floor(x / 2^i) = 2 floor(x / 2^(i+1)) + bit, the level-i window starts T0 + bit
+// entries into that run.
+template <int RB, int R, int MODE> struct pair_info {
+  using WI = win_info<RB, R, MODE>;
+  static constexpr int NT = WI::NT, EXT = WI::EXT, NW = WI::NW;
+  static constexpr int NW2 = 2 * NW;
+  static constexpr int T0 = R + EXT;
+  static constexpr int NBLK = (RB - 2 + NW2 + RB - 1) / RB;  // 16-byte blocks the run can touch
+  static constexpr int ND = NBLK * 4;
+};
+
+// d[0..ND): the blocks of the run; o: (even) position of its first entry inside the first block.
+// lo[m] = entry T0 + bit + m of the run (the level-i window), hi[j] = mean of entries 2j, 2j+1 rounded to the
+// storage type (the level-(i+1) window): the arithmetic of the build's epilogue and of avg_pool2d on a
+// 16-bit volume (fp32 mean of the stored values, one rounding).
+template <typename VT, int NW, int ND, int T0>
+__device__ __forceinline__ void decode_pair(uint32_t (&d)[ND], int o, int bit, float (&lo)[NW], float (&hi)[NW]) {
+  if constexpr (sizeof(VT) == 4) {
+    static_assert(2 * NW + 2 <= ND, "run does not fit its blocks");
+    const bool s2 = (o & 2) != 0;  // o is 0 or 2
+#pragma unroll
+    for (int k = 0; k < 2 * NW; ++k) {
+      const uint32_t a = d[k], b = d[k + 2];
+      d[k] = s2 ? b : a;
+    }
+#pragma unroll
+    for (int j = 0; j < NW; ++j) hi[j] = 0.5f * (__uint_as_float(d[2 * j]) + __uint_as_float(d[2 * j + 1]));
+    const bool b1 = bit != 0;
+#pragma unroll
+    for (int m = 0; m < NW; ++m) {
+      const uint32_t a = d[T0 + m], b = d[T0 + 1 + m];
+      lo[m] = __uint_as_float(b1 ? b : a);
+    }
+  } else {
+    static_assert(NW + 3 <= ND, "run does not fit its blocks");
+    const int sh = o >> 1;  // shift in dwords, 0..3
+    const bool s2 = (sh & 2) != 0, s1 = (sh & 1) != 0;
+#pragma unroll
+    for (int k = 0; k <= NW; ++k) {
+      const uint32_t a = d[k], b = d[k + 2];
+      d[k] = s2 ? b : a;
+    }
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+      const uint32_t a = d[k], b = d[k + 1];
+      d[k] = s1 ? b : a;
+    }
+#pragma unroll
+    for (int j = 0; j < NW; ++j)
+      hi[j] = rc_round_as<VT>(0.5f * (half_bits_to_float(d[j] & 0xffffu, VT()) + half_bits_to_float(d[j] >> 16, VT())));
+    // the level-i window starts at element T0 + bit of the run: a byte permute of two neighbouring dwords
+    constexpr int K0 = T0 / 2;
+    constexpr uint32_t SEL0 = (T0 & 1) ? 0x05040302u : 0x03020100u, SEL1 = (T0 & 1) ? 0x07060504u : 0x05040302u;
+    const uint32_t sel = bit ? SEL1 : SEL0;
+#pragma unroll
+    for (int p = 0; 2 * p < NW; ++p) {
+      const uint32_t t = __builtin_amdgcn_perm(d[K0 + p + 1], d[K0 + p], sel);
+      lo[2 * p] = half_bits_to_float(t & 0xffffu, VT());
+      lo[2 * p + 1] = half_bits_to_float(t >> 16, VT());
+    }
+  }
+}
+
+// The 2r+1 taps of one level from its window entries v[0..NW) (entry m is column wbase + m of the level,
+// already zero outside the image): floor + lerp (sampler_kernel.cu:42-57) or the reference's grid_sample
+// coordinate round trip (core/corr.py:137, core/utils/utils.py:63), whose fp32 rounding can move a tap across
+// an integer -- the window is one entry wider on both sides for that.
+template <int R, int MODE, int NW>
+__device__ __forceinline__ void interp_taps(const float (&v)[NW], int wbase, int Wi, float xi, float frac,
+                                            float (&tap)[2 * R + 1]) {
+  constexpr int NT = 2 * R + 1, EXT = MODE == RC_COORD_GRIDSAMPLE ? 1 : 0;
+  if constexpr (MODE == RC_COORD_EXACT) {
+    const float a = frac, bw = 1.0f - a;
+#pragma unroll
+    for (int k = 0; k < NT; ++k) tap[k] = v[k] * bw + v[k + 1] * a;
+  } else {
+    const float wm1 = (float)(Wi - 1);
+    int dlt[NT];  // where grid_sample's floor landed relative to tap k: -1, 0 or +1
+    float w0[NT], w1w[NT];
+    bool odd = false;
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+      int i0k;
+      rc_gridsample_coords(xi, k - R, wm1, &i0k, &w0[k], &w1w[k]);
+      dlt[k] = i0k - (wbase + EXT + k);
+      odd |= (dlt[k] != 0);
+    }
+    if (__builtin_expect(__any(odd), 0)) {
+#pragma unroll
+      for (int k = 0; k < NT; ++k) {
+        const float va = dlt[k] < 0 ? v[k] : (dlt[k] > 0 ? v[k + 2] : v[k + 1]);
+        const float vb = dlt[k] < 0 ? v[k + 1] : (dlt[k] > 0 ? v[k + 3] : v[k + 2]);
+        tap[k] = va * w0[k] + vb * w1w[k];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NT; ++k) tap[k] = v[k + EXT] * w0[k] + v[k + EXT + 1] * w1w[k];
+    }
+  }
+}
+
+// Loads of one window / run: NBLK 16-byte blocks of level `lvl_base` (wave-uniform base of this image row's
+// slab), branch-free: lanes whose window ends early re-read their last block.
+template <int NBLK>
+__device__ __forceinline__ void load_blocks(uint32_t (&d)[NBLK * 4], const char* lvl_base, const win_pos& pos, int nb,
+                                            uint32_t blk_bytes, int w1) {
+  const bool tiny = nb < NBLK;
+#pragma unroll
+  for (int k = 0; k < NBLK; ++k) {
+    const uint32_t sb = row_step(pos.sb0, (uint32_t)min(k, pos.nbk), (uint32_t)nb, tiny);
+    const uint4 q = *reinterpret_cast<const uint4*>(lvl_base + (__umul24(sb, blk_bytes) + (uint32_t)w1 * 16u));
+    d[4 * k + 0] = q.x;
+    d[4 * k + 1] = q.y;
+    d[4 * k + 2] = q.z;
+    d[4 * k + 3] = q.w;
+  }
+}
+
+// Everything one pixel needs from levels i (stored) and i + 1 (derived) of a forward pyramid
+template <typename VT, int R, int MODE> struct pair_fetch {
+  static constexpr int RB = vt_info<VT>::RB, LG = vt_info<VT>::LG;
+  using PI = pair_info<RB, R, MODE>;
+  uint32_t d[PI::ND];
+  win_pos pos;        // of the run at level i
+  int s_lo, s_hi;     // first window entry (column) at level i / i + 1
+  float x_lo, x_hi;   // the level coordinates
+  float f_lo, f_hi;   // their fractional parts
+
+  __device__ __forceinline__ void issue(const VT* vol, const rc_dev_layout& lay, int i, float x, int w1, int bh,
+                                        uint32_t blk_bytes) {
+    const int nb = lay.widthp[i] >> LG;
+    x_lo = x * (1.0f / (float)(1 << i));
+    x_hi = x * (0.5f / (float)(1 << i));
+    const float fl = floorf(x_lo), fh = floorf(x_hi);
+    f_lo = x_lo - fl;
+    f_hi = x_hi - fh;
+    s_lo = rc_safe_int(fl) - R - PI::EXT;
+    s_hi = rc_safe_int(fh) - R - PI::EXT;
+    pos = locate_window<RB, LG, PI::NW2>(2 * s_hi, w1, i, lay.width[i], nb, lay.bias[i]);
+    const char* lvl = reinterpret_cast<const char*>(vol) +
+                      uniform(lay.offset[i] * (int64_t)sizeof(VT) + (int64_t)bh * nb * blk_bytes);
+    load_blocks<PI::NBLK>(d, lvl, pos, nb, blk_bytes, w1);
+  }
+
+  // window entries of both levels, zero outside the image
+  __device__ __forceinline__ void windows(const rc_dev_layout& lay, int i, float (&lo)[PI::NW], float (&hi)[PI::NW]) {
+    const int Wlo = lay.width[i], Whi = lay.width[i + 1];
+    decode_pair<VT, PI::NW, PI::ND, PI::T0>(d, pos.o, (s_lo - 2 * s_hi - PI::T0) & 1, lo, hi);
+    const bool edge = (s_lo < 0) || (s_lo + PI::NW > Wlo) || (s_hi < 0) || (s_hi + PI::NW > Whi);
+    if (__any(edge)) {  // interior waves skip the zero padding
+#pragma unroll
+      for (int m = 0; m < PI::NW; ++m) {
+        lo[m] = ((unsigned)(s_lo + m) < (unsigned)Wlo) ? lo[m] : 0.f;
+        hi[m] = ((unsigned)(s_hi + m) < (unsigned)Whi) ? hi[m] : 0.f;
+      }
+    }
+  }
+};
+
+// The same for a stored level read alone (the last level of a pyramid with an odd level count)
+template <typename VT, int R, int MODE> struct single_fetch {
+  static constexpr int RB = vt_info<VT>::RB, LG = vt_info<VT>::LG;
+  using WI = win_info<RB, R, MODE>;
+  uint32_t d[WI::ND];
+  win_pos pos;
+  float xi, frac;
+
+  __device__ __forceinline__ void issue(const VT* vol, const rc_dev_layout& lay, int i, float x, int w1, int bh,
+                                        uint32_t blk_bytes) {
+    const int nb = lay.widthp[i] >> LG;
+    xi = x * (1.0f / (float)(1 << i));
+    const float xf = floorf(xi);
+    frac = xi - xf;
+    pos = locate_window<RB, LG, WI::NW>(rc_safe_int(xf) - R - WI::EXT, w1, i, lay.width[i], nb, lay.bias[i]);
+    const char* lvl = reinterpret_cast<const char*>(vol) +
+                      uniform(lay.offset[i] * (int64_t)sizeof(VT) + (int64_t)bh * nb * blk_bytes);
+    load_blocks<WI::NBLK>(d, lvl, pos, nb, blk_bytes, w1);
+  }
+
+  __device__ __forceinline__ void window(const rc_dev_layout& lay, int i, float (&v)[WI::NW]) {
+    decode_window<VT, WI::NW, WI::ND>(d, pos.o, v);
+    if (__any(pos.edge)) {
+#pragma unroll
+      for (int m = 0; m < WI::NW; ++m) v[m] = ((unsigned)(pos.wbase + m) < (unsigned)lay.width[i]) ? v[m] : 0.f;
+    }
+  }
+};
+
 // bias[i]: the smallest multiple of the level's block-row count that keeps
 // g0 - (w1 >> i) / RB + nb - RC_WRAP_ROWS / RB non-negative for every window that overlaps the image
 inline void set_row_bias(rc_dev_layout& d, int rb, int nw) {

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), name
-    assert _lib.lib.rc_version() == 100
+    assert _lib.lib.rc_version() == _lib.RC_VERSION == int(re.search(r"#define RC_VERSION (\d+)", hdr).group(1))
 
 
 def test_layout_matches_documented_formula():
@@ -32,11 +32,24 @@ def test_layout_matches_documented_formula():
     assert lib.rc_pyramid_layout(8, 96, 312, 312, 4, RC_F16, lay) == 0
     assert lay.pitch == 320 and lay.rb == 8 and lay.dtype == RC_F16
     assert list(lay.width) == [312, 156, 78, 39] and list(lay.widthp) == [312, 160, 80, 40]
+    # a forward pyramid keeps its even levels (the lookup derives levels 1 and 3 in registers) ...
     off = 0
-    for i in range(4):
+    assert list(lay.stored) == [1, 0, 1, 0] and lay.full == 0
+    for i in (0, 2):
         assert lay.offset[i] == off
         off += 8 * 96 * lay.widthp[i] * lay.pitch
-    assert lay.total == off
+    assert lay.total == off and lay.offset[1] == 0 and lay.offset[3] == 0
+    # ... the float gradient pyramid of rc_lookup_bwd every level
+    glay = Layout()
+    assert lib.rc_grad_pyramid_layout(8, 96, 312, 312, 4, glay) == 0
+    assert list(glay.stored) == [1, 1, 1, 1] and glay.full == 1 and glay.rb == 4 and glay.dtype == RC_F32
+    off = 0
+    for i in range(4):
+        assert glay.offset[i] == off
+        off += 8 * 96 * glay.widthp[i] * glay.pitch
+    assert glay.total == off
+    assert lib.rc_lookup_bwd(16, 2, 16, 16, lay, 4, 0, None) == -1          # needs the gradient layout
+    assert lib.rc_lookup_fwd(16, glay, 16, 2, 16, 4, 0, None) == -1         # needs the forward layout
     assert lib.rc_pyramid_layout(8, 96, 312, 312, 4, RC_F32, lay) == 0 and lay.rb == 4
     assert lib.rc_pyramid_layout(1, 1, 16, 4, 4, RC_F32, lay) != 0          # W2 too small for 4 levels
     assert b"too small" in lib.rc_last_error_string()

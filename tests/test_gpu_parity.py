@@ -263,6 +263,17 @@ def test_full_size_properties(R, dtype, shape):
     centre = torch.gather(lvl0, 3, idx.unsqueeze(-1))[..., 0]
     ok = ((xs - disp) >= 0)[:, 0]
     assert torch.equal(out[:, 4][ok], centre[ok])
+    #     levels 1 and 3 are not in memory: the lookup derives them from levels 0 and 2 in registers, and at
+    #     x divisible by 2^i the centre tap of level i must be the pooled entry bit for bit (fp32 mean of the
+    #     stored values, rounded to the storage type -- avg_pool2d on a 16-bit volume, core/corr.py:42)
+    assert [bool(s) for s in blk.layout.stored[:4]] == [True, False, True, False]
+    for i in range(1, 4):
+        lvl = blk.dense_level(i).float()
+        xi = (xs - disp)[:, 0]
+        sel = ok & (xi.long() % (1 << i) == 0) & ((xi.long() >> i) < lvl.shape[-1])
+        assert int(sel.sum()) > 100
+        ci = torch.gather(lvl, 3, (xi.long() >> i).clamp(0, lvl.shape[-1] - 1).unsqueeze(-1))[..., 0]
+        assert torch.equal(out[:, 9 * i + 4][sel], ci[sel]), f"level {i}"
     # (c) linearity of the lookup in the volume and agreement of alt with reg on device
     c2 = torch.from_numpy(O.synthetic_coords(B, H, W, seed=5)).cuda()
     reg = blk(c2)
