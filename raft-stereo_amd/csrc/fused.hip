@@ -115,7 +115,7 @@ __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __r
                                                                    int coords_channels,
                                                                    const VT* __restrict__ wpack,
                                                                    const float* __restrict__ bias,
-                                                                   VT* __restrict__ out, int chunks_per_row,
+                                                                   VT* __restrict__ out, int chunks_per_image,
                                                                    int n_items, int relu) {
   constexpr bool IS16 = sizeof(VT) == 2;
   using PF = pair_fetch<VT, R, MODE>;
@@ -125,19 +125,17 @@ __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __r
   static_assert(NT <= FC_SLOTS, "a level's taps must fit its slots");
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int item = blockIdx.x * (FC_THREADS / 64) + wave;  // (row, 64-pixel chunk), wave-uniform
+  const int item = blockIdx.x * (FC_THREADS / 64) + wave;  // (image, 64-pixel chunk), wave-uniform
   if (item >= n_items) return;
-  const int bh = item / chunks_per_row;
-  const int c0 = (item - bh * chunks_per_row) * 64;
-  const int b = bh / lay.H, h = bh - b * lay.H;
+  const px_item it = locate_item(item, chunks_per_image, lay.H, lay.W1, lane);
+  const int b = it.b, h = it.h, w1g = it.w1;  // lanes past the end of the image repeat its last pixel (never stored)
   const int64_t HW = (int64_t)lay.H * lay.W1;
   const int g = lane >> 4;
   const uint32_t blk_bytes = (uint32_t)lay.pitch * 16u;
   const int L = lay.L;
-  const int w1g = min(c0 + lane, lay.W1 - 1);  // pixels past the row end repeat the last one (never stored)
 
   // ---- phase 1: the plain lookup's gather, lane = pixel: taps of every level in registers
-  const float x = (coords + uniform(((int64_t)b * coords_channels) * HW + (int64_t)h * lay.W1))[w1g];
+  const float x = (coords + uniform(((int64_t)b * coords_channels) * HW))[min(it.p0 + lane, (int)HW - 1)];
   float tap[RC_MAX_LEVELS][NT];
 #pragma unroll
   for (int i = 0; i < RC_MAX_LEVELS; ++i)
@@ -145,8 +143,8 @@ __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __r
     for (int k = 0; k < NT; ++k) tap[i][k] = 0.f;
   if (L == 4) {  // both runs in flight together
     PF p0, p2;
-    p0.issue(vol, lay, 0, x, w1g, bh, blk_bytes);
-    p2.issue(vol, lay, 2, x, w1g, bh, blk_bytes);
+    p0.issue(vol, lay, 0, x, w1g, h, b, blk_bytes);
+    p2.issue(vol, lay, 2, x, w1g, h, b, blk_bytes);
     float lo[NW], hi[NW];
     p0.windows(lay, 0, lo, hi);
     interp_taps<R, MODE, NW>(lo, p0.s_lo, lay.width[0], p0.x_lo, p0.f_lo, tap[0]);
@@ -157,7 +155,7 @@ __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __r
   } else {
     if (L >= 2) {
       PF pf;
-      pf.issue(vol, lay, 0, x, w1g, bh, blk_bytes);
+      pf.issue(vol, lay, 0, x, w1g, h, b, blk_bytes);
       float lo[NW], hi[NW];
       pf.windows(lay, 0, lo, hi);
       interp_taps<R, MODE, NW>(lo, pf.s_lo, lay.width[0], pf.x_lo, pf.f_lo, tap[0]);
@@ -165,14 +163,14 @@ __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __r
     }
     if (L == 1) {
       SF sf;
-      sf.issue(vol, lay, 0, x, w1g, bh, blk_bytes);
+      sf.issue(vol, lay, 0, x, w1g, h, b, blk_bytes);
       float v[NW];
       sf.window(lay, 0, v);
       interp_taps<R, MODE, NW>(v, sf.pos.wbase, lay.width[0], sf.xi, sf.frac, tap[0]);
     }
     if (L == 3) {
       SF sf;
-      sf.issue(vol, lay, 2, x, w1g, bh, blk_bytes);
+      sf.issue(vol, lay, 2, x, w1g, h, b, blk_bytes);
       float v[NW];
       sf.window(lay, 2, v);
       interp_taps<R, MODE, NW>(v, sf.pos.wbase, lay.width[2], sf.xi, sf.frac, tap[2]);
@@ -240,12 +238,12 @@ __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __r
   }
 
   // ---- phase 3: lane rows <-> passes, so that lane = pixel; activation; one run per channel plane
-  const int w1 = c0 + lane;
-  VT* orow = out + uniform(((int64_t)b * FC_OUT) * HW + (int64_t)h * lay.W1 + c0);
+  const int pix = it.p0 + lane;  // flattened pixel of this lane
+  VT* orow = out + uniform(((int64_t)b * FC_OUT) * HW + it.p0);
   // 16-bit outputs leave as dwords when rows start on even pixels: neighbouring lanes trade one
   // channel each (even lanes keep the first channel of a pair for pixels (l, l+1), odd lanes the
   // second for (l-1, l)), so one store instruction writes two 128-byte runs
-  const bool pairs = IS16 && (lay.W1 & 1) == 0 && (reinterpret_cast<uintptr_t>(out) & 3) == 0;
+  const bool pairs = IS16 && (HW & 1) == 0 && (reinterpret_cast<uintptr_t>(out) & 3) == 0;
   const bool odd = lane & 1;
   const int64_t plane_b = HW * (int64_t)sizeof(VT);
 #pragma unroll
@@ -273,7 +271,7 @@ __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __r
             char* dst = reinterpret_cast<char*>(orow) + uniform((int64_t)ca * plane_b);
             const uint32_t voff =
                 (odd ? (uint32_t)(4 * plane_b) : 0u) + (uint32_t)(lane & ~1) * (uint32_t)sizeof(VT);
-            if ((w1 & ~1) < lay.W1) *reinterpret_cast<uint32_t*>(dst + voff) = word;
+            if ((pix & ~1) < (int)HW) *reinterpret_cast<uint32_t*>(dst + voff) = word;
           }
           stored = true;
         }
@@ -281,7 +279,7 @@ __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __r
       if (!stored) {
 #pragma unroll
         for (int s = 0; s < 4; ++s)
-          if (w1 < lay.W1) (orow + uniform((int64_t)(16 * t + 4 * s + r) * HW))[lane] = rc_from_float<VT>(xs[s]);
+          if (pix < (int)HW) (orow + uniform((int64_t)(16 * t + 4 * s + r) * HW))[lane] = rc_from_float<VT>(xs[s]);
       }
     }
   }
@@ -290,8 +288,8 @@ __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __r
 template <typename VT, int R>
 int launch_fused(const void* vol, rc_dev_layout d, const float* coords, int cc, const void* wpack,
                  const float* bias, void* out, int mode, int relu, hipStream_t st) {
-  const int chunks = (d.W1 + 63) / 64;
-  const int n_items = (int)((int64_t)d.B * d.H * chunks);
+  const int chunks = (d.H * d.W1 + 63) / 64;
+  const int n_items = (int)((int64_t)d.B * chunks);
   const int blocks = (n_items + (FC_THREADS / 64) - 1) / (FC_THREADS / 64);
   if (mode == RC_COORD_EXACT) {
     set_row_bias(d, vt_info<VT>::RB, pair_info<vt_info<VT>::RB, R, RC_COORD_EXACT>::NW2);

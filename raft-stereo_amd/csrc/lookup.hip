@@ -27,69 +27,71 @@ struct lk_update {
   float* flow_out;     // [B,2,H,W1]
 };
 
-// Stores the 2r+1 taps of one level: one 256-byte run per channel plane and wave
-template <int NT>
+// Stores the 2r+1 taps of one level: one aligned 256-byte piece per channel plane and wave.  NTS: non-temporal
+// stores, for outputs far larger than the caches (they are read once, by the next kernel).
+template <int NT, bool NTS>
 __device__ __forceinline__ void store_taps(float* __restrict__ out, int64_t plane0, int64_t HW, int lane,
                                            const float (&tap)[NT]) {
 #pragma unroll
-  for (int k = 0; k < NT; ++k) (out + uniform(plane0 + k * HW))[lane] = tap[k];
+  for (int k = 0; k < NT; ++k) {
+    float* dst = (out + uniform(plane0 + k * HW)) + lane;
+    if constexpr (NTS) __builtin_nontemporal_store(tap[k], dst);
+    else *dst = tap[k];
+  }
 }
 
 // A forward pyramid keeps its even levels; levels (i, i+1) are served by one run of level i (pair_fetch in
 // window.h).  ALL4 (the model's configuration, 4 levels): the 16-byte loads of both runs are issued back to
 // back, then decoded, interpolated and stored.  Otherwise one pair (or the odd last level) at a time.
-template <typename VT, int R, int MODE, bool ALL4>
+template <typename VT, int R, int MODE, bool ALL4, bool NTS>
 __global__ __launch_bounds__(LK_THREADS) void lookup_fwd_kernel(const VT* __restrict__ vol,
                                                                 rc_dev_layout lay,
                                                                 const float* __restrict__ coords,
                                                                 int coords_channels,
                                                                 float* __restrict__ out,
-                                                                int chunks_per_row, int n_items, lk_update upd) {
+                                                                int chunks_per_image, int n_items, lk_update upd) {
   using PF = pair_fetch<VT, R, MODE>;
   using SF = single_fetch<VT, R, MODE>;
   constexpr int NT = 2 * R + 1, NW = PF::PI::NW;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int item = blockIdx.x * (LK_THREADS / 64) + wave;  // (row, 64-pixel chunk), wave-uniform
+  const int item = blockIdx.x * (LK_THREADS / 64) + wave;  // (image, 64-pixel chunk), wave-uniform
   if (item >= n_items) return;
-  const int bh = item / chunks_per_row;
-  const int c0 = (item - bh * chunks_per_row) * 64;
-  const int w1 = c0 + lane;
-  if (w1 >= lay.W1) return;
-  const int b = bh / lay.H, h = bh - b * lay.H;
+  const px_item it = locate_item(item, chunks_per_image, lay.H, lay.W1, lane);
+  if (!it.live) return;
+  const int b = it.b, h = it.h, w1 = it.w1;
   const int64_t HW = (int64_t)lay.H * lay.W1;
   const int L = ALL4 ? 4 : lay.L;
   const uint32_t blk_bytes = (uint32_t)lay.pitch * 16u;  // distance between block rows of a pixel
 
-  float x = (coords + uniform(((int64_t)b * coords_channels) * HW + (int64_t)h * lay.W1 + c0))[lane];
+  float x = (coords + uniform(((int64_t)b * coords_channels) * HW + it.p0))[lane];
   if (upd.delta) {  // wave-uniform: the GRU iteration's coordinate update folded into this lookup
     // core/raft_stereo.py:120-123 (delta_flow[:,1] = 0; coords1 = coords1 + delta_flow) and :111
     // (flow = coords1 - coords0, coords0 = the pixel grid of core/utils/utils.py coords_grid)
-    const int64_t p0 = uniform(((int64_t)b * 2) * HW + (int64_t)h * lay.W1 + c0);
-    x += (upd.delta + p0)[lane];
-    const float y = coords_channels > 1
-                        ? (coords + uniform(((int64_t)b * coords_channels + 1) * HW + (int64_t)h * lay.W1 + c0))[lane]
-                        : (float)h;
-    (upd.coords_out + p0)[lane] = x;
-    (upd.coords_out + uniform(p0 + HW))[lane] = y;
-    (upd.flow_out + p0)[lane] = x - (float)w1;
-    (upd.flow_out + uniform(p0 + HW))[lane] = y - (float)h;
+    const int64_t q0 = uniform(((int64_t)b * 2) * HW + it.p0);
+    x += (upd.delta + q0)[lane];
+    const float y = coords_channels > 1 ? (coords + uniform(((int64_t)b * coords_channels + 1) * HW + it.p0))[lane]
+                                        : (float)h;
+    (upd.coords_out + q0)[lane] = x;
+    (upd.coords_out + uniform(q0 + HW))[lane] = y;
+    (upd.flow_out + q0)[lane] = x - (float)w1;
+    (upd.flow_out + uniform(q0 + HW))[lane] = y - (float)h;
   }
-  const int64_t out_u = ((int64_t)b * L * NT) * HW + (int64_t)h * lay.W1 + c0;  // wave-uniform
+  const int64_t out_u = ((int64_t)b * L * NT) * HW + it.p0;  // wave-uniform
 
   auto finish_pair = [&](PF& pf, int i) {
     float lo[NW], hi[NW], tap[NT];
     pf.windows(lay, i, lo, hi);
     interp_taps<R, MODE, NW>(lo, pf.s_lo, lay.width[i], pf.x_lo, pf.f_lo, tap);
-    store_taps<NT>(out, out_u + (int64_t)i * NT * HW, HW, lane, tap);
+    store_taps<NT, NTS>(out, out_u + (int64_t)i * NT * HW, HW, lane, tap);
     interp_taps<R, MODE, NW>(hi, pf.s_hi, lay.width[i + 1], pf.x_hi, pf.f_hi, tap);
-    store_taps<NT>(out, out_u + (int64_t)(i + 1) * NT * HW, HW, lane, tap);
+    store_taps<NT, NTS>(out, out_u + (int64_t)(i + 1) * NT * HW, HW, lane, tap);
   };
 
   if constexpr (ALL4) {
     PF p0, p2;
-    p0.issue(vol, lay, 0, x, w1, bh, blk_bytes);
-    p2.issue(vol, lay, 2, x, w1, bh, blk_bytes);
+    p0.issue(vol, lay, 0, x, w1, h, b, blk_bytes);
+    p2.issue(vol, lay, 2, x, w1, h, b, blk_bytes);
     finish_pair(p0, 0);
     finish_pair(p2, 2);
   } else {
@@ -97,18 +99,18 @@ __global__ __launch_bounds__(LK_THREADS) void lookup_fwd_kernel(const VT* __rest
     for (int i = 0; i + 1 < RC_MAX_LEVELS; i += 2) {
       if (i + 1 < L) {  // wave-uniform
         PF pf;
-        pf.issue(vol, lay, i, x, w1, bh, blk_bytes);
+        pf.issue(vol, lay, i, x, w1, h, b, blk_bytes);
         finish_pair(pf, i);
       }
     }
     if (L & 1) {  // the last level stands alone
       const int i = L - 1;
       SF sf;
-      sf.issue(vol, lay, i, x, w1, bh, blk_bytes);
+      sf.issue(vol, lay, i, x, w1, h, b, blk_bytes);
       float v[NW], tap[NT];
       sf.window(lay, i, v);
       interp_taps<R, MODE, NW>(v, sf.pos.wbase, lay.width[i], sf.xi, sf.frac, tap);
-      store_taps<NT>(out, out_u + (int64_t)i * NT * HW, HW, lane, tap);
+      store_taps<NT, NTS>(out, out_u + (int64_t)i * NT * HW, HW, lane, tap);
     }
   }
 }
@@ -506,20 +508,32 @@ int dispatch_adjoint_dense(const adj_lists& lists, const adj_dims& d, void* dC, 
   return RC_EUNSUPPORTED;
 }
 
+// Outputs beyond this size cannot stay in the 256 MiB Infinity Cache until their consumer reads them: they
+// are written with non-temporal stores (KITTI, 64 pairs: 104 -> 94 us).  Smaller outputs keep plain stores:
+// non-temporal ones make this kernel faster there too (8 pairs: 12.2 -> 10.5 us) but the consumer then
+// reads from HBM and loses twice that (lookup + cast + convc1: 102.9 -> 106.3 us), measured in bench.py.
+constexpr int64_t LK_NT_STORE_BYTES = 160ll << 20;
+
 template <typename VT, int R, int MODE>
 int launch_fwd_mode(const void* vol, rc_dev_layout d, const float* coords, int cc, float* out, hipStream_t st,
                     const lk_update& upd) {
   using PI = pair_info<vt_info<VT>::RB, R, MODE>;
   set_row_bias(d, vt_info<VT>::RB, PI::NW2);
-  const int chunks = (d.W1 + 63) / 64;
-  const int n_items = (int)((int64_t)d.B * d.H * chunks);
+  const int chunks = (d.H * d.W1 + 63) / 64;
+  const int n_items = (int)((int64_t)d.B * chunks);
   const int blocks = (n_items + (LK_THREADS / 64) - 1) / (LK_THREADS / 64);
-  if (R == 4 && d.L == 4)  // the model's configuration: all levels' loads in flight together
-    hipLaunchKernelGGL((lookup_fwd_kernel<VT, R, MODE, R == 4>), dim3(blocks), dim3(LK_THREADS), 0, st,
-                       (const VT*)vol, d, coords, cc, out, chunks, n_items, upd);
-  else
-    hipLaunchKernelGGL((lookup_fwd_kernel<VT, R, MODE, false>), dim3(blocks), dim3(LK_THREADS), 0, st, (const VT*)vol,
-                       d, coords, cc, out, chunks, n_items, upd);
+  const bool nts = (int64_t)d.B * d.L * (2 * R + 1) * d.H * d.W1 * 4 > LK_NT_STORE_BYTES;
+#define RC_LK(ALL4, NTS)                                                                                       \
+  hipLaunchKernelGGL((lookup_fwd_kernel<VT, R, MODE, ALL4, NTS>), dim3(blocks), dim3(LK_THREADS), 0, st,      \
+                     (const VT*)vol, d, coords, cc, out, chunks, n_items, upd)
+  if (R == 4 && d.L == 4) {  // the model's configuration: all levels' loads in flight together
+    if (nts) RC_LK((R == 4), true);
+    else RC_LK((R == 4), false);
+  } else {
+    if (nts) RC_LK(false, true);
+    else RC_LK(false, false);
+  }
+#undef RC_LK
   return rc_check_launch("rc_lookup_fwd");
 }
 

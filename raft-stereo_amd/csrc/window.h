@@ -213,16 +213,18 @@ __device__ __forceinline__ void interp_taps(const float (&v)[NW], int wbase, int
   }
 }
 
-// Loads of one window / run: NBLK 16-byte blocks of level `lvl_base` (wave-uniform base of this image row's
-// slab), branch-free: lanes whose window ends early re-read their last block.
+// Loads of one window / run: NBLK 16-byte blocks of level `lvl_base` (wave-uniform base of the level's slab
+// of this IMAGE), branch-free: lanes whose window ends early re-read their last block.  `h` is the lane's
+// image row: a wave owns 64 consecutive pixels of the flattened image, so it may straddle two rows.
 template <int NBLK>
 __device__ __forceinline__ void load_blocks(uint32_t (&d)[NBLK * 4], const char* lvl_base, const win_pos& pos, int nb,
-                                            uint32_t blk_bytes, int w1) {
+                                            uint32_t blk_bytes, int w1, int h) {
   const bool tiny = nb < NBLK;
+  const uint32_t row0 = (uint32_t)h * (uint32_t)nb;
 #pragma unroll
   for (int k = 0; k < NBLK; ++k) {
     const uint32_t sb = row_step(pos.sb0, (uint32_t)min(k, pos.nbk), (uint32_t)nb, tiny);
-    const uint4 q = *reinterpret_cast<const uint4*>(lvl_base + (__umul24(sb, blk_bytes) + (uint32_t)w1 * 16u));
+    const uint4 q = *reinterpret_cast<const uint4*>(lvl_base + (__umul24(row0 + sb, blk_bytes) + (uint32_t)w1 * 16u));
     d[4 * k + 0] = q.x;
     d[4 * k + 1] = q.y;
     d[4 * k + 2] = q.z;
@@ -240,7 +242,8 @@ template <typename VT, int R, int MODE> struct pair_fetch {
   float x_lo, x_hi;   // the level coordinates
   float f_lo, f_hi;   // their fractional parts
 
-  __device__ __forceinline__ void issue(const VT* vol, const rc_dev_layout& lay, int i, float x, int w1, int bh,
+  // b: image (wave-uniform); h, w1: the lane's pixel
+  __device__ __forceinline__ void issue(const VT* vol, const rc_dev_layout& lay, int i, float x, int w1, int h, int b,
                                         uint32_t blk_bytes) {
     const int nb = lay.widthp[i] >> LG;
     x_lo = x * (1.0f / (float)(1 << i));
@@ -252,8 +255,8 @@ template <typename VT, int R, int MODE> struct pair_fetch {
     s_hi = rc_safe_int(fh) - R - PI::EXT;
     pos = locate_window<RB, LG, PI::NW2>(2 * s_hi, w1, i, lay.width[i], nb, lay.bias[i]);
     const char* lvl = reinterpret_cast<const char*>(vol) +
-                      uniform(lay.offset[i] * (int64_t)sizeof(VT) + (int64_t)bh * nb * blk_bytes);
-    load_blocks<PI::NBLK>(d, lvl, pos, nb, blk_bytes, w1);
+                      uniform(lay.offset[i] * (int64_t)sizeof(VT) + (int64_t)b * lay.H * nb * blk_bytes);
+    load_blocks<PI::NBLK>(d, lvl, pos, nb, blk_bytes, w1, h);
   }
 
   // window entries of both levels, zero outside the image
@@ -279,7 +282,7 @@ template <typename VT, int R, int MODE> struct single_fetch {
   win_pos pos;
   float xi, frac;
 
-  __device__ __forceinline__ void issue(const VT* vol, const rc_dev_layout& lay, int i, float x, int w1, int bh,
+  __device__ __forceinline__ void issue(const VT* vol, const rc_dev_layout& lay, int i, float x, int w1, int h, int b,
                                         uint32_t blk_bytes) {
     const int nb = lay.widthp[i] >> LG;
     xi = x * (1.0f / (float)(1 << i));
@@ -287,8 +290,8 @@ template <typename VT, int R, int MODE> struct single_fetch {
     frac = xi - xf;
     pos = locate_window<RB, LG, WI::NW>(rc_safe_int(xf) - R - WI::EXT, w1, i, lay.width[i], nb, lay.bias[i]);
     const char* lvl = reinterpret_cast<const char*>(vol) +
-                      uniform(lay.offset[i] * (int64_t)sizeof(VT) + (int64_t)bh * nb * blk_bytes);
-    load_blocks<WI::NBLK>(d, lvl, pos, nb, blk_bytes, w1);
+                      uniform(lay.offset[i] * (int64_t)sizeof(VT) + (int64_t)b * lay.H * nb * blk_bytes);
+    load_blocks<WI::NBLK>(d, lvl, pos, nb, blk_bytes, w1, h);
   }
 
   __device__ __forceinline__ void window(const rc_dev_layout& lay, int i, float (&v)[WI::NW]) {
@@ -299,6 +302,28 @@ template <typename VT, int R, int MODE> struct single_fetch {
     }
   }
 };
+
+// A wave's share of a lookup: 64 consecutive pixels of the flattened image b (pixel = h * W1 + w1), so
+// that every channel plane of the output [B, C, H, W1] is written in whole, aligned 256-byte pieces whatever
+// W1 is (row-aligned chunks leave every row's last wave part empty and share cache lines between waves).
+struct px_item {
+  int b;        // image (wave-uniform)
+  int p0;       // first flattened pixel (wave-uniform, a multiple of 64)
+  int h, w1;    // the lane's pixel (the last pixel of the image for lanes past its end)
+  bool live;    // the lane has a pixel
+};
+__device__ __forceinline__ px_item locate_item(int item, int chunks_per_image, int H, int W1, int lane) {
+  px_item it;
+  it.b = item / chunks_per_image;
+  it.p0 = (item - it.b * chunks_per_image) * 64;
+  const int HW = H * W1;
+  const int p = it.p0 + lane;
+  it.live = p < HW;
+  const int pc = min(p, HW - 1);
+  it.h = pc / W1;
+  it.w1 = pc - it.h * W1;
+  return it;
+}
 
 // bias[i]: the smallest multiple of the level's block-row count that keeps
 // g0 - (w1 >> i) / RB + nb - RC_WRAP_ROWS / RB non-negative for every window that overlaps the image
@@ -325,9 +350,11 @@ inline int check_common(const rc_layout* lay, const void* a, const void* b, cons
     RC_REQUIRE(lay->width[lay->L - 1] >= 2, RC_EINVAL,
                "grid_sample coordinates need every level at least 2 wide (W2=%lld, L=%d)",
                (long long)lay->W2, lay->L);
-  RC_REQUIRE((int64_t)lay->B * lay->H * ((lay->W1 + 63) / 64) < (1ll << 31), RC_EINVAL, "too many pixels");
-  RC_REQUIRE(lay->pitch < (1 << 20) && (int64_t)(lay->widthp[0] / lay->rb + 1) * lay->pitch * 16 < (1ll << 31),
-             RC_EINVAL, "one image row of the pyramid exceeds the 32-bit lane offset range");
+  RC_REQUIRE((int64_t)lay->B * ((lay->H * lay->W1 + 63) / 64) < (1ll << 31) && lay->H * lay->W1 < (1ll << 30), RC_EINVAL,
+             "too many pixels");
+  RC_REQUIRE(lay->pitch < (1 << 20) && lay->H * (int64_t)(lay->widthp[0] / lay->rb + 1) < (1ll << 24) &&
+                 lay->H * (int64_t)(lay->widthp[0] / lay->rb + 1) * lay->pitch * 16 < (1ll << 32),
+             RC_EINVAL, "one image's level 0 exceeds the 32-bit lane offset range (4 GiB)");
   RC_REQUIRE((uintptr_t)a % 16 == 0, RC_EINVAL, "pyramid pointer must be 16-byte aligned");
   return RC_OK;
 }
