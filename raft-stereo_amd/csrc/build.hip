@@ -18,6 +18,12 @@
 #include <math.h>
 #include <type_traits>
 
+// Ablation switches for tools/lab_build.hip only (the library is built with 0): 1 = no pyramid stores,
+// 2 = no MFMA, 4 = no f2 loads after the first two chunks
+#ifndef RC_LAB_ABLATE
+#define RC_LAB_ABLATE 0
+#endif
+
 namespace {
 
 constexpr int BT = 256;    // threads per workgroup
@@ -60,24 +66,25 @@ template <typename T> struct build_cfg {
 // end of a row is read element by element.
 typedef uint32_t u4v_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
-template <typename T, int FAST>
-__device__ __forceinline__ void stage_load(u4v (&regs)[8], const T* __restrict__ rowbase, int64_t kstride,
+template <typename T, int FAST, int NP = 8>
+__device__ __forceinline__ void stage_load(u4v (&regs)[NP], const T* __restrict__ rowbase, int64_t kstride,
                                            int W, int n0, int D) {
   constexpr int EPS = 16 / sizeof(T);
+  constexpr int RPP = KMAX / NP;  // rows per pass = threads / 8
   const int seg = threadIdx.x & 7, kr = threadIdx.x >> 3;
   const int col = n0 + seg * EPS;
   if constexpr (FAST) {
     if (FAST == 2 || col + EPS <= W || col >= W) {  // FAST == 2: W is a multiple of the segment
       const uint32_t voff = ((uint32_t)kr * (uint32_t)kstride + (uint32_t)(col >= W ? 0 : col)) * (uint32_t)sizeof(T);
 #pragma unroll
-      for (int p = 0; p < 8; ++p) {
-        const char* src = reinterpret_cast<const char*>(rowbase) + (int64_t)p * 32 * kstride * (int64_t)sizeof(T);
+      for (int p = 0; p < NP; ++p) {
+        const char* src = reinterpret_cast<const char*>(rowbase) + (int64_t)p * RPP * kstride * (int64_t)sizeof(T);
         regs[p] = *reinterpret_cast<const u4v_a4*>(src + voff);
       }
     } else {
 #pragma unroll
-      for (int p = 0; p < 8; ++p) {
-        const T* src = rowbase + (int64_t)(p * 32 + kr) * kstride + col;
+      for (int p = 0; p < NP; ++p) {
+        const T* src = rowbase + (int64_t)(p * RPP + kr) * kstride + col;
         alignas(16) T tmp[EPS];
 #pragma unroll
         for (int e = 0; e < EPS; ++e) tmp[e] = (col + e < W) ? src[e] : (T)0.0f;
@@ -86,8 +93,8 @@ __device__ __forceinline__ void stage_load(u4v (&regs)[8], const T* __restrict__
     }
   } else {
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const int k = p * 32 + kr;
+    for (int p = 0; p < NP; ++p) {
+      const int k = p * RPP + kr;
       u4v v = (u4v)(0u);
       if (k < D) {
         const T* src = rowbase + (int64_t)k * kstride + col;
@@ -101,13 +108,13 @@ __device__ __forceinline__ void stage_load(u4v (&regs)[8], const T* __restrict__
   }
 }
 
-template <typename T, int PF>
-__device__ __forceinline__ void stage_store(const u4v (&regs)[8], T* ldsF) {
+template <typename T, int PF, int NP = 8>
+__device__ __forceinline__ void stage_store(const u4v (&regs)[NP], T* ldsF) {
   constexpr int EPS = 16 / sizeof(T);
   const int seg = threadIdx.x & 7, kr = threadIdx.x >> 3;
 #pragma unroll
-  for (int p = 0; p < 8; ++p) {
-    const int k = p * 32 + kr;
+  for (int p = 0; p < NP; ++p) {
+    const int k = p * (KMAX / NP) + kr;
     *reinterpret_cast<u4v*>(ldsF + k * PF + seg * EPS) = regs[p];
   }
 }
@@ -189,6 +196,10 @@ template <typename VT> struct out_map {
   }
   __device__ __forceinline__ bool ok(int i, int col, int G) const { return col < W1 && (uint32_t)G < nb[i]; }
   __device__ __forceinline__ void store16(int i, int col, int G, uint32_t a, uint32_t b, uint32_t c, uint32_t d) const {
+    if constexpr (RC_LAB_ABLATE & 1) {
+      asm volatile("" ::"v"(a), "v"(b), "v"(c), "v"(d), "v"(offset(i, col, G)));
+      return;
+    }
     if (ok(i, col, G)) {
       const u4v v = {a, b, c, d};
       __builtin_nontemporal_store(v, reinterpret_cast<u4v*>(base[i] + offset(i, col, G)));
@@ -270,6 +281,156 @@ __device__ __forceinline__ void epilogue32(const f4v& a00, const f4v& a01, const
   for (int j = 0; j < 4; ++j) r[j] = __float_as_uint(p2[j >> 1][j & 1]);
   transpose_rows(r);  // lane row j: the level-2 block of (column tile j & 1, row tile j >> 1)
   om.store16(2, col_sw, (n0 >> 4) + (g >> 1), r[0], r[1], r[2], r[3]);
+}
+
+// ---- epilogue of a 64 (w2) x 16 (w1) wave tile of a 16-bit pyramid (build16_kernel): acc[rt], lane (g, li) holds
+// rows n0 + 16 rt + 4 g + {0..3} of column cw + li: eight level-0 blocks and two level-2 blocks per column.
+template <typename VT>
+__device__ __forceinline__ void epilogue16_col(const f4v (&acc)[4], float scale, const out_map<VT>& om, int L, int n0,
+                                               int cw) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
+  const int col = cw + li;
+  float p2[4];  // level 2: one value per row tile (level 1, its two parents, is not stored)
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    uint32_t x[2][2];  // [row tile 2m + e][half]: 4 rows = half a level-0 block
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const f4v& a = acc[2 * m + e];
+      x[e][0] = pack2<VT>(a[0] * scale, a[1] * scale);
+      x[e][1] = pack2<VT>(a[2] * scale, a[3] * scale);
+      const uint32_t q1 = pack2<VT>(0.5f * (unpack_lo<VT>(x[e][0]) + unpack_hi<VT>(x[e][0])),
+                                    0.5f * (unpack_lo<VT>(x[e][1]) + unpack_hi<VT>(x[e][1])));
+      p2[2 * m + e] = 0.5f * (unpack_lo<VT>(q1) + unpack_hi<VT>(q1));
+    }
+    // lane rows (0,1) and (2,3) pair their 4-row halves: afterwards lane row g holds the whole block
+    // (row tile 2m + (g & 1), rows 8 (g >> 1) .. + 8) in x[0][0], x[0][1], x[1][0], x[1][1]
+    swap16(x[0][0], x[1][0]);
+    swap16(x[0][1], x[1][1]);
+    om.store16(0, col, ((n0 + 16 * (2 * m + (g & 1))) >> 3) + (g >> 1), x[0][0], x[0][1], x[1][0], x[1][1]);
+  }
+  if (L < 3) return;
+  // level 2: block m holds the values of row tiles 2m, 2m + 1; w[m] = (element g, element 4 + g)
+  uint32_t w[4];
+  w[0] = pack2<VT>(p2[0], p2[1]);
+  w[1] = pack2<VT>(p2[2], p2[3]);
+  w[2] = w[3] = 0u;
+  transpose_rows(w);  // lane row j < 2: w[p] = elements (p, 4 + p) of block j
+  const uint32_t d0 = __builtin_amdgcn_perm(w[1], w[0], 0x05040100u), d1 = __builtin_amdgcn_perm(w[3], w[2], 0x05040100u);
+  const uint32_t d2 = __builtin_amdgcn_perm(w[1], w[0], 0x07060302u), d3 = __builtin_amdgcn_perm(w[3], w[2], 0x07060302u);
+  if (g < 2) om.store16(2, col, (n0 >> 5) + g, d0, d1, d2, d3);
+}
+
+// ---- 16-bit feature maps, 16-bit pyramid (the mixed-precision configuration).  One workgroup = 8 waves owns
+// one image row x 128 w1, 16 columns per wave, and sweeps w2 in chunks of 64.  Two staged chunks are in flight
+// in registers while a third is multiplied out of LDS, so the HBM latency of the f2 stream is covered from
+// inside the workgroup (with one chunk in flight the waves spent half their time waiting: rocprof,
+// profiles/r01).  A wave's f1 fragments are 32 registers, which leaves room for the second chunk at 4 waves
+// per SIMD; the price, every f2 fragment feeding one MFMA instead of two, is LDS bandwidth the kernel has to
+// spare (it is bound by HBM).
+constexpr int BT16 = 512;
+constexpr int TW16 = 16;
+
+template <typename T, int FAST>
+__global__ __launch_bounds__(BT16, 4) void build16_kernel(const T* __restrict__ f1, const T* __restrict__ f2,
+                                                          T* __restrict__ vol, rc_dev_layout lay, int D, float scale,
+                                                          int n_tiles, int n_rows) {
+  using C = build_cfg<T>;
+  constexpr int NP = 4;  // staging passes of 64 rows
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* ldsF = reinterpret_cast<T*>(smem);
+
+  // XCD-aware mapping: the tiles of one image row get block ids congruent mod 8 (one XCD, one L2)
+  const int id = blockIdx.x;
+  const int j = id >> 3;
+  const int row = (j / n_tiles) * 8 + (id & 7);
+  const int tile = j % n_tiles;
+  if (row >= n_rows) return;
+  const int b = row / lay.H, h = row - b * lay.H;
+  const int c0 = tile * TM;
+  const int W1 = lay.W1, W2 = lay.W2, L = lay.L;
+
+  const int wave = threadIdx.x >> 6;
+  const int cw = c0 + wave * TW16;  // first w1 column of this wave
+  const int nk = FAST ? C::NKS : (D + C::KSTEP - 1) / C::KSTEP;
+
+  const T* f1row = f1 + ((int64_t)b * D * lay.H + h) * W1;
+  const T* f2row = f2 + ((int64_t)b * D * lay.H + h) * W2;
+  const int64_t ks1 = (int64_t)lay.H * W1, ks2 = (int64_t)lay.H * W2;
+  const int n_chunks = (W2 + C::TN - 1) / C::TN;
+
+  T* const buf0 = ldsF;
+  T* const buf1 = ldsF + C::LDS_BYTES / (int)sizeof(T);
+  u4v regs[2][NP];
+  s8v bfrag[C::NKS];
+  {
+    // both halves (64 columns each) of the f1 tile and the first two f2 chunks are requested before anything is
+    // waited for; the halves go through the two staging buffers side by side
+    u4v fa[NP], fb[NP];
+    stage_load<T, FAST, NP>(fa, f1row, ks1, W1, c0, D);
+    stage_load<T, FAST, NP>(fb, f1row, ks1, W1, c0 + 64, D);
+    stage_load<T, FAST, NP>(regs[0], f2row, ks2, W2, 0, D);
+    if (n_chunks > 1) stage_load<T, FAST, NP>(regs[1], f2row, ks2, W2, C::TN, D);
+    stage_store<T, C::PF, NP>(fa, buf0);
+    stage_store<T, C::PF, NP>(fb, buf1);
+    __syncthreads();
+    const short* src = reinterpret_cast<const short*>((wave >> 2) ? buf1 : buf0);
+#pragma unroll
+    for (int kb = 0; kb < C::NKS; ++kb)
+      bfrag[kb] = kb < nk ? tr_frag<C::PF>(src, kb, (wave & 3) * TW16) : (s8v)(0);
+    __syncthreads();  // the fragments have been read: the buffers are free for f2
+    stage_store<T, C::PF, NP>(regs[0], buf0);
+    if (n_chunks > 2) stage_load<T, FAST, NP>(regs[0], f2row, ks2, W2, 2 * C::TN, D);
+  }
+
+  out_map<T> om;
+  om.blk_bytes = (uint32_t)lay.pitch * 16u;
+  om.W1 = W1;
+#pragma unroll
+  for (int i = 0; i < RC_MAX_LEVELS; ++i) {
+    const int nb = lay.widthp[i < L ? i : 0] >> out_map<T>::LG;
+    om.nb[i] = (uint32_t)nb;
+    om.kb[i] = (uint32_t)(lay.bias[i < L ? i : 0] - RC_WRAP_ROWS / out_map<T>::RB);
+    om.slowmod[i] = lay.bias[i < L ? i : 0] > 3 * nb;
+    om.base[i] = reinterpret_cast<char*>(vol) +
+                 (lay.offset[i < L ? i : 0] * (int64_t)sizeof(T) + (int64_t)row * nb * om.blk_bytes);
+  }
+
+  // Chunk c is multiplied out of staging buffer c & 1 while chunk c + 1 (register set `nxt`) moves into the
+  // other one and chunk c + 3 is requested into the registers it frees: one barrier per chunk, and neither
+  // the LDS stores nor the wait for the global loads sit between the barrier and the MFMAs.
+  auto chunk = [&](u4v (&nxt)[NP], int c, const T* cur_buf, T* nxt_buf) {
+    const int n0 = c * C::TN;
+    __syncthreads();  // chunk c is in cur_buf; everybody is done reading nxt_buf (chunk c - 1)
+    const bool active = cw < W1;  // wave-uniform: a wave past the row end only helps with the staging
+    f4v acc[4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) acc[rt] = (f4v)(0.f);
+    if (active) {
+#pragma unroll
+      for (int kb = 0; kb < C::NKS; ++kb) {
+        if (kb < nk) {
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) {
+            if constexpr (RC_LAB_ABLATE & 2) {
+              if (kb == 0) acc[rt][0] += (float)reinterpret_cast<const short*>(cur_buf)[threadIdx.x + rt] + (float)bfrag[rt][0];
+            } else {
+              acc[rt] = mfma16<T>(tr_frag<C::PF>(reinterpret_cast<const short*>(cur_buf), kb, rt * 16), bfrag[kb], acc[rt]);
+            }
+          }
+        }
+      }
+    }
+    if (c + 1 < n_chunks) {
+      stage_store<T, C::PF, NP>(nxt, nxt_buf);
+      if (c + 3 < n_chunks && !(RC_LAB_ABLATE & 4)) stage_load<T, FAST, NP>(nxt, f2row, ks2, W2, n0 + 3 * C::TN, D);
+    }
+    if (active) epilogue16_col<T>(acc, scale, om, L, n0, cw);
+  };
+  for (int c = 0; c < n_chunks; c += 2) {
+    chunk(regs[1], c, buf0, buf1);
+    if (c + 1 < n_chunks) chunk(regs[0], c + 1, buf1, buf0);
+  }
 }
 
 template <typename T, typename VT, int FAST>
@@ -496,6 +657,17 @@ int launch_build(const void* f1, const void* f2, void* vol, const rc_layout* lay
     if (e == hipSuccess)
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(&build_kernel<T, VT, 2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    if constexpr (C::IS16 && std::is_same<T, VT>::value) {
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&build16_kernel<T, 0>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * C::LDS_BYTES);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&build16_kernel<T, 1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * C::LDS_BYTES);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&build16_kernel<T, 2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * C::LDS_BYTES);
+    }
     if (e != hipSuccess) {
       rc_set_error("hipFuncSetAttribute(%d bytes LDS): %s", C::LDS_BYTES, hipGetErrorString(e));
       return (int)e;
@@ -517,10 +689,20 @@ int launch_build(const void* f1, const void* f2, void* vol, const rc_layout* lay
 #define RC_LAUNCH_BUILD(F)                                                                               \
   hipLaunchKernelGGL((build_kernel<T, VT, F>), dim3((unsigned)blocks), dim3(BT), C::LDS_BYTES, st, (const T*)f1, \
                      (const T*)f2, (VT*)vol, d, D, scale, n_tiles, n_rows)
-  if (fast && whole) RC_LAUNCH_BUILD(2);
-  else if (fast) RC_LAUNCH_BUILD(1);
-  else RC_LAUNCH_BUILD(0);
+#define RC_LAUNCH_BUILD16(F)                                                                             \
+  hipLaunchKernelGGL((build16_kernel<T, F>), dim3((unsigned)blocks), dim3(BT16), 2 * C::LDS_BYTES, st, (const T*)f1, \
+                     (const T*)f2, (T*)vol, d, D, scale, n_tiles, n_rows)
+  if constexpr (C::IS16 && std::is_same<T, VT>::value) {
+    if (fast && whole) RC_LAUNCH_BUILD16(2);
+    else if (fast) RC_LAUNCH_BUILD16(1);
+    else RC_LAUNCH_BUILD16(0);
+  } else {
+    if (fast && whole) RC_LAUNCH_BUILD(2);
+    else if (fast) RC_LAUNCH_BUILD(1);
+    else RC_LAUNCH_BUILD(0);
+  }
 #undef RC_LAUNCH_BUILD
+#undef RC_LAUNCH_BUILD16
   return rc_check_launch("rc_build_pyramid");
 }
 
