@@ -5,8 +5,9 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer owned by the caller; the library never allocates,
- *     frees or keeps a pointer past the call, and holds no global state besides a
- *     thread-local error string;
+ *     frees or keeps a pointer past the call.  Its only state is a thread-local error string
+ *     and, per device, the flags "this kernel's dynamic-LDS limit has been raised"
+ *     (hipFuncSetAttribute is idempotent, so racing first calls are harmless);
  *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream);
  *   - every function returns 0 on success, a negative RC_E* code for argument errors, or a
  *     positive hipError_t for launch errors; rc_last_error_string() explains the last
@@ -51,6 +52,8 @@ extern "C" {
 #define RC_MAX_FUSED_LOOKUPS 32  /* lookups one rc_lookup_bwd_dense call can take */
 #define RC_CONVC1_OUT 64         /* output channels of the motion encoder's convc1 (core/update.py:71) */
 #define RC_CONVC1_MAX_RADIUS 7   /* rc_lookup_convc1_fwd: a level's 2r+1 taps must fit 16 MFMA K slots */
+#define RC_SAMPLER_MAX_RADIUS 7  /* rc_sampler_fwd/bwd: a pixel's 2r+2 taps are served by a quarter wave (16 lanes) */
+#define RC_ALT_MAX_RADIUS 6      /* rc_alt_fwd: the union of 16 pixels' tap windows must fit the wave's MFMA tiles */
 
 /* element types of feature maps / volumes */
 enum { RC_F32 = 0, RC_F16 = 1, RC_BF16 = 2 };

@@ -16,6 +16,8 @@ the upstream tree, which is NOT shipped):
   corr_volume_bwd    adjoint of corr_volume
   alt_lookup         core/corr.py:64-107 (on-the-fly variant; equal to reg by linearity)
   convc1_relu(_bwd)  core/update.py:71,78 (first layer of the motion encoder on a lookup result)
+  sampler_fwd/bwd_rounded  sampler/sampler_kernel.cu:39-58, :83-103 with a 16-bit scalar_t (every product
+                     and sum rounded to the storage type)
 
 Parity pin: the functions are checked in tests/test_oracle_golden.py against vectors
 captured from the reference's own Python (tests/golden/make_golden.py ran
@@ -252,6 +254,55 @@ def convc1_relu_bwd(corr, weight, bias, grad_act, relu=True):
 
 
 # ----------------------------------------------------------------------------- helpers
+def sampler_fwd_rounded(volume, coords, radius, rnd):
+    """sampler_forward_kernel with `scalar_t` a 16-bit type (sampler/sampler_kernel.cu:39-58): the lerp
+    weights are converted to scalar_t (:53, :56), every product is rounded to scalar_t and `+=` rounds the
+    sum again.  `rnd` rounds a float32 array to the storage type and back (np.float16 round trip, or
+    round_bf16).  volume [B,H,W1,W2] (values already representable), coords [B,>=1,H,W1] -> [B,2r+1,H,W1]."""
+    vol = np.asarray(volume, dtype=F32)
+    x0 = np.asarray(coords, dtype=F32)[:, 0]
+    B, H, W1, W2 = vol.shape
+    fx = np.floor(x0)
+    dx = (x0 - fx).astype(F32)
+    wa, wb = rnd((F32(1.0) - dx).astype(F32)), rnd(dx)
+    base = np.where(np.abs(fx) < 1e8, fx, -2.0 ** 28).astype(np.int64) - radius
+    rd = 2 * radius + 1
+    s = np.zeros((B, H, W1, rd + 1), dtype=F32)
+    for i in range(rd + 1):
+        x1 = base + i
+        ok = (x1 >= 0) & (x1 < W2)
+        s[..., i] = np.where(ok, np.take_along_axis(vol, np.clip(x1, 0, W2 - 1)[..., None], axis=3)[..., 0], 0)
+    out = np.zeros((B, rd, H, W1), dtype=F32)
+    for k in range(rd):
+        out[:, k] = rnd(rnd(s[..., k] * wa) + rnd(s[..., k + 1] * wb))
+    return out
+
+
+def sampler_bwd_rounded(coords, corr_grad, W2, radius, rnd):
+    """sampler_backward_kernel with a 16-bit scalar_t (sampler/sampler_kernel.cu:83-103): g = 0;
+    g += corr_grad[i-1] * scalar_t(dx); g += corr_grad[i] * scalar_t(1 - dx), each product and each sum rounded
+    to scalar_t; volume_grad is zero elsewhere.  corr_grad [B,2r+1,H,W1] -> [B,H,W1,W2]."""
+    g = np.asarray(corr_grad, dtype=F32)
+    x0 = np.asarray(coords, dtype=F32)[:, 0]
+    B, rd, H, W1 = g.shape
+    fx = np.floor(x0)
+    dx = (x0 - fx).astype(F32)
+    wa, wb = rnd((F32(1.0) - dx).astype(F32)), rnd(dx)
+    base = np.where(np.abs(fx) < 1e8, fx, -2.0 ** 28).astype(np.int64) - radius
+    out = np.zeros((B, H, W1, W2), dtype=F32)
+    for i in range(rd + 1):
+        acc = np.zeros((B, H, W1), dtype=F32)
+        if i > 0:
+            acc = rnd(acc + rnd(g[:, i - 1] * wb))
+        if i < rd:
+            acc = rnd(acc + rnd(g[:, i] * wa))
+        x1 = base + i
+        ok = (x1 >= 0) & (x1 < W2)
+        bi, hi, wi = np.nonzero(ok)
+        out[bi, hi, wi, x1[ok]] = acc[ok]
+    return out
+
+
 def rel_to_max(a, b):
     """The parity metric of SURVEY.md 8(d): max|a-b| / max|b|."""
     a = np.asarray(a, dtype=np.float64)

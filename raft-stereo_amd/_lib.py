@@ -11,6 +11,8 @@ RC_MAX_RADIUS = 8
 RC_MAX_FUSED_LOOKUPS = 32
 RC_CONVC1_OUT = 64
 RC_CONVC1_MAX_RADIUS = 7
+RC_SAMPLER_MAX_RADIUS = 7
+RC_ALT_MAX_RADIUS = 6
 RC_F32, RC_F16, RC_BF16 = 0, 1, 2
 RC_COORD_EXACT, RC_COORD_GRIDSAMPLE = 0, 1
 RC_WRAP_ROWS = 32

@@ -362,8 +362,8 @@ class AltCorrBlock1DHip:
 
     def __init__(self, fmap1, fmap2, num_levels=4, radius=4, coord_mode=None):
         B, D, H, W1, W2 = _check_fmaps(fmap1, fmap2, num_levels, radius)
-        if radius > 6:
-            raise ValueError("alt_hip supports radius <= 6")
+        if radius > _lib.RC_ALT_MAX_RADIUS:
+            raise ValueError(f"alt_hip supports radius <= {_lib.RC_ALT_MAX_RADIUS}")
         self.num_levels, self.radius = num_levels, radius
         self.B, self.D, self.H, self.W1, self.W2 = B, D, H, W1, W2
         self.device = fmap1.device

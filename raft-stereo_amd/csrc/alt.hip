@@ -279,7 +279,7 @@ int dispatch_alt(const void* f1t, const void* f2t, const alt_dev_layout& d, cons
     case 5: return launch_alt<T, 5>(f1t, f2t, d, coords, cc, out, mode, st);
     case 6: return launch_alt<T, 6>(f1t, f2t, d, coords, cc, out, mode, st);
   }
-  rc_set_error("alt: radius %d outside 1..6", radius);
+  rc_set_error("alt: radius %d outside 1..%d", radius, RC_ALT_MAX_RADIUS);
   return RC_EUNSUPPORTED;
 }
 

@@ -83,7 +83,8 @@ int check_args(const void* a, const void* b, const void* c, int cc, int64_t B, i
   RC_REQUIRE(a && b && c, RC_EINVAL, "null pointer argument");
   RC_REQUIRE(B > 0 && H > 0 && W1 > 0 && W2 > 0, RC_EINVAL, "non-positive size");
   RC_REQUIRE(cc >= 1, RC_EINVAL, "coords must have at least one channel");
-  RC_REQUIRE(radius >= 1 && 2 * radius + 2 <= 16, RC_EUNSUPPORTED, "radius %d outside 1..7", radius);
+  RC_REQUIRE(radius >= 1 && radius <= RC_SAMPLER_MAX_RADIUS, RC_EUNSUPPORTED, "corr_sampler: radius %d outside 1..%d", radius,
+             RC_SAMPLER_MAX_RADIUS);
   RC_REQUIRE(B * H * W1 < (1ll << 40) && W2 < (1ll << 30), RC_EINVAL, "sizes exceed index range");
   return RC_OK;
 }

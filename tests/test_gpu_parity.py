@@ -236,6 +236,47 @@ def test_sampler_twin_forward_backward(R, golden, case, kind):
         R.corr_sampler_hip.forward(vol.detach().transpose(2, 3), coords, r)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("case", ["tiny_b2_d32_h3_w24", "odd_b1_d64_h2_w40x45"])
+@pytest.mark.parametrize("kind", KINDS)
+def test_sampler_twin_16bit_rounds_like_scalar_t(R, golden, case, kind, dtype):
+    """The reference's kernels do their arithmetic in scalar_t (sampler_kernel.cu:50-56, :94-102): under AMP
+    the lerp weights, every product and every `+=` are rounded to fp16.  The twin must reproduce those
+    roundings bit for bit (fp32 products of two 11-bit significands are exact, so rounding them once is what
+    the half multiply does).  bf16 has no dispatch in the reference (:126); the twin extends the same rule."""
+    g = golden(case)
+    r = int(g["r"])
+    rnd = (lambda a: np.asarray(a, np.float32).astype(np.float16).astype(np.float32)) if dtype == torch.float16 \
+        else O.round_bf16
+    for i in range(2):
+        vol16 = dev(g[f"level{i}"], dtype)
+        coords = (g[f"coords_{kind}"] / 2 ** i).astype(np.float32)
+        out, = R.corr_sampler_hip.forward(vol16, dev(coords), r)
+        assert out.dtype == dtype
+        ref = O.sampler_fwd_rounded(vol16.float().cpu().numpy(), coords, r, rnd)
+        assert np.array_equal(out.float().cpu().numpy(), ref), float(np.abs(out.float().cpu().numpy() - ref).max())
+        gout16 = dev(g[f"gout_{kind}"][:, :2 * r + 1], dtype)
+        gv, = R.corr_sampler_hip.backward(vol16, dev(coords), gout16, r)
+        rg = O.sampler_bwd_rounded(coords, gout16.float().cpu().numpy(), vol16.shape[-1], r, rnd)
+        assert np.array_equal(gv.float().cpu().numpy(), rg), float(np.abs(gv.float().cpu().numpy() - rg).max())
+
+
+def test_sampler_twin_argument_checks(R):
+    """sampler.cpp:20-22 CHECK_INPUT and the accessor types (packed_accessor32<float,4> for coords) raise on a
+    wrong dtype or shape; the twin must not launch on them either."""
+    vol = torch.zeros((1, 2, 8, 8), device="cuda", dtype=torch.float16)
+    coords = torch.zeros((1, 2, 2, 8), device="cuda")
+    g = torch.zeros((1, 9, 2, 8), device="cuda", dtype=torch.float16)
+    for bad in (lambda: R.corr_sampler_hip.backward(vol, coords.half(), g, 4),
+                lambda: R.corr_sampler_hip.backward(vol, coords, g[:, :7].contiguous(), 4),
+                lambda: R.corr_sampler_hip.backward(vol, coords[:, :, :1].contiguous(), g, 4),
+                lambda: R.corr_sampler_hip.backward(vol, coords, g.float(), 4),
+                lambda: R.corr_sampler_hip.forward(vol, coords.double(), 4),
+                lambda: R.corr_sampler_hip.forward(vol, coords, 8)):
+        with pytest.raises(RuntimeError):
+            bad()
+
+
 # ------------------------------------------------------------------ full-size properties (BASELINE configs)
 @pytest.mark.parametrize("dtype,shape", [(torch.float16, (8, 256, 96, 312)), (torch.float32, (1, 256, 96, 128)),
                                          (torch.float16, (1, 256, 60, 80)), (torch.bfloat16, (8, 256, 80, 180))])
@@ -290,6 +331,44 @@ def test_full_size_properties(R, dtype, shape):
         # correlation is linear in f1: <d/df1, E> = <lookup(C(E, f2)), G>
         rhs = float((R.CorrBlock1DHip(eps_dir.to(dtype), f2, num_levels=4, radius=4)(c2) * G).sum())
         assert abs(lhs - rhs) <= 2e-2 * max(abs(lhs), abs(rhs), 1.0)
+
+
+def test_middlebury_full_size_alt_and_row_slabs(R):
+    """BASELINE config 5: one Middlebury-F pair (2016x3008 padded, /4 -> [1,256,504,752] fp16) through `alt_hip`
+    (core/corr.py:64-107, volume never built): (a) image rows against the oracle, (b) far-out-of-range
+    coordinates give zeros, (c) the north star's row-slab claim: the 8 x 63-row split of shard_rows(504, 8, k)
+    reproduces the full frame's rows bit for bit with no exchange between slabs, (d) the radius limit the
+    header declares is enforced."""
+    from raft_stereo_amd import _lib
+    B, D, H, W, L, r = 1, 256, 504, 752, 4, 4
+    gen = torch.Generator(device="cuda").manual_seed(55)
+    f1 = torch.randn((B, D, H, W), generator=gen, device="cuda").half()
+    f2 = torch.randn((B, D, H, W), generator=gen, device="cuda").half()
+    coords_np = O.synthetic_coords(B, H, W, seed=11)
+    coords = torch.from_numpy(coords_np).cuda()
+    alt = R.make_corr_fn("alt_hip", f1, f2, radius=r, num_levels=L)
+    assert alt.volume is None
+    full = alt(coords)
+    assert tuple(full.shape) == (B, L * (2 * r + 1), H, W) and full.dtype == torch.float32
+    # (a) three image rows against the fp32 oracle on the rounded inputs (fp16 bar of SURVEY 8d)
+    for h in (0, 251, 503):
+        a, b = f1[:, :, h:h + 1].float().cpu().numpy(), f2[:, :, h:h + 1].float().cpu().numpy()
+        ref = O.lookup_exact(O.pool_pyramid(O.corr_volume(a, b), L), coords_np[:, :, h:h + 1], r)
+        assert rel(full[:, :, h:h + 1], ref) < TOL16[torch.float16], f"row {h}"
+    # (b) nothing in reach -> zeros (grid_sample's zero padding / within_bounds of sampler_kernel.cu:49)
+    far = coords.clone()
+    far[:, 0] = 1.0e6
+    far[:, 0, :, ::2] = -1.0e6
+    assert float(alt(far).abs().max()) == 0.0
+    # (c) row slabs: each rank's slab of both feature maps and of coords, nothing shared
+    for k in range(8):
+        r0, r1 = R.shard_rows(H, 8, k)
+        assert r1 - r0 == 63
+        slab = R.make_corr_fn("alt_hip", f1[:, :, r0:r1], f2[:, :, r0:r1], radius=r, num_levels=L)
+        assert torch.equal(slab(coords[:, :, r0:r1].contiguous()), full[:, :, r0:r1]), f"slab {k}"
+    # (d)
+    with pytest.raises(ValueError):
+        R.AltCorrBlock1DHip(f1[:, :, :2], f2[:, :, :2], num_levels=L, radius=_lib.RC_ALT_MAX_RADIUS + 1)
 
 
 # ------------------------------------------------------------------ fused adjoint vs the pyramid adjoint

@@ -238,3 +238,23 @@ def test_pool2x_and_interp_match_reference(golden):
         assert U.rel_to_max(U.interp(g[k], *ref.shape[2:]), ref) <= 1e-6, k
         i = k[len("interp_in"):]
         assert U.rel_to_max(U.interp_bwd(g["interp_cot" + i], *g[k].shape[2:]), g["interp_grad" + i]) <= 1e-5, k
+
+
+def test_rounded_sampler_oracle_reduces_to_the_exact_lookup():
+    """sampler_fwd/bwd_rounded (the scalar_t arithmetic of sampler_kernel.cu:50-56, :94-102) with the identity as
+    rounding function are the plain floor + lerp lookup and its adjoint of one level."""
+    import numpy as np
+    from oracle import corr_oracle as O
+    rng = np.random.default_rng(5)
+    vol = rng.standard_normal((2, 3, 7, 19)).astype(np.float32)
+    coords = np.stack([rng.uniform(-6, 25, (2, 3, 7)), np.zeros((2, 3, 7))], 1).astype(np.float32)
+    coords[0, 0, 0, 0], coords[0, 0, 0, 1] = 4.0, 1e9
+    ident = lambda a: np.asarray(a, np.float32)
+    out = O.sampler_fwd_rounded(vol, coords, 3, ident)
+    assert O.rel_to_max(out, O.lookup_exact([vol], coords, 3)) < 1e-6
+    g = rng.standard_normal(out.shape).astype(np.float32)
+    gv = O.sampler_bwd_rounded(coords, g, 19, 3, ident)
+    assert O.rel_to_max(gv, O.lookup_bwd(coords, g, [19], 3, O.EXACT)[0]) < 1e-6
+    assert abs(float((out * g).sum()) - float((vol * gv).sum())) < 1e-3          # adjoint identity
+    half = lambda a: np.asarray(a, np.float32).astype(np.float16).astype(np.float32)
+    assert np.abs(O.sampler_fwd_rounded(half(vol), coords, 3, half) - out).max() < 2e-2
