@@ -232,6 +232,20 @@ int rc_convc1_bwd(const float* corr, const void* act, const void* grad_act, cons
                   int in_channels, int64_t HW, int dtype, int relu, void* stream);
 
 /*
+ * rc_convc1_bwd for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments and results as
+ * rc_convc1_bwd minus `work`: the scratch (transposed weights + block partials) is a file-scope device array
+ * of the library, 4 539 392 bytes, which every GPU the library runs on holds until the process ends.  The
+ * call allocates nothing (no hipMalloc / hipFree, no allocating library routine).  Limit: in_channels <= 68
+ * (= RC_MAX_LEVELS * (2 * RC_MAX_RADIUS + 1), what the array is sized for); a wider input is refused with
+ * RC_EUNSUPPORTED.  All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams,
+ * two host threads) race; calls on one stream, or on different GPUs, do not.
+ */
+int rc_convc1_bwd_static(const float* corr, const void* act, const void* grad_act, const float* weight,
+                         float* grad_corr, float* grad_weight, float* grad_bias, int64_t B, int in_channels,
+                         int64_t HW, int dtype, int relu, void* stream);
+
+/*
  * Drop-in for the reference's `corr_sampler` extension (sampler/sampler.cpp:48-51): one
  * level, the caller's row-major volume [B,H,W1,W2] of `dtype`, coords [B,coords_channels,H,W1]
  * float, corr / corr_grad [B,2r+1,H,W1] of `dtype`.  rc_sampler_bwd OVERWRITES volume_grad

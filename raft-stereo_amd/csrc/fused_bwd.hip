@@ -17,6 +17,8 @@
 // convc1_bwd_reduce_kernel (no atomics, reproducible run to run).
 #include "rc_common.h"
 
+#include <mutex>
+
 namespace {
 
 constexpr int CB_OUT = RC_CONVC1_OUT;                              // 64 output channels
@@ -442,4 +444,52 @@ extern "C" int rc_convc1_bwd(const float* corr, const void* act, const void* gra
   }
   rc_set_error("unknown dtype %d", dtype);
   return RC_EUNSUPPORTED;
+}
+
+// ---- the same adjoint for callers that cannot allocate (code under HIP graph capture, serving loops, harnesses
+// that forbid hipMalloc): the workspace is a file-scope device array.  Every GPU the library runs on holds
+// its own copy of the array at its own address until the process ends; the address is looked up once per
+// device, with that device current, and from then on only that pointer is used on the host side (the
+// array's name is a host-side stand-in, not a device address).
+namespace {
+constexpr size_t CB_SCRATCH_BYTES =
+    ((size_t)CB_KMAX * CB_OUT + (size_t)CB_BLOCKS * (CB_OUT * CB_KMAX + CB_OUT)) * sizeof(float);  // 4 539 392 B
+constexpr int CB_MAX_DEVICES = 64;
+}  // namespace
+static __device__ __align__(256) unsigned char scratch[CB_SCRATCH_BYTES];
+static void* g_scratch_ptr[CB_MAX_DEVICES];     // per device, set once (under g_scratch_lock)
+static std::mutex g_scratch_lock;
+
+extern "C" int rc_convc1_bwd_static(const float* corr, const void* act, const void* grad_act, const float* weight,
+                                    float* grad_corr, float* grad_weight, float* grad_bias, int64_t B,
+                                    int in_channels, int64_t HW, int dtype, int relu, void* stream) {
+  // the scratch array is sized for the widest convolution input the library supports; anything wider would
+  // overrun it, so it is refused here, before any device work
+  RC_REQUIRE(in_channels >= 1 && in_channels <= CB_KMAX, RC_EUNSUPPORTED,
+             "rc_convc1_bwd_static: in_channels %d exceeds the static scratch buffer's maximum of %d "
+             "(%zu bytes per device)", in_channels, CB_KMAX, CB_SCRATCH_BYTES);
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess || dev < 0 || dev >= CB_MAX_DEVICES) {
+    rc_set_error("rc_convc1_bwd_static: no current HIP device (or its index is >= %d)", CB_MAX_DEVICES);
+    return RC_ENODEVICE;
+  }
+  void* ptr;
+  {
+    std::lock_guard<std::mutex> hold(g_scratch_lock);
+    if (!g_scratch_ptr[dev]) {
+      void* p = nullptr;
+      e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));   // this device's copy (the device is current)
+      if (e != hipSuccess || !p) {
+        rc_set_error("rc_convc1_bwd_static: hipGetSymbolAddress failed: %s", hipGetErrorString(e));
+        return e != hipSuccess ? (int)e : RC_ENODEVICE;
+      }
+      g_scratch_ptr[dev] = p;
+    }
+    ptr = g_scratch_ptr[dev];
+  }
+  // nothing in the buffer has to start at zero: the pack / transpose kernels write the weights' part and
+  // every partial-sum slot the reduction reads is written by this call's own blocks first
+  return rc_convc1_bwd(corr, act, grad_act, weight, grad_corr, grad_weight, grad_bias, ptr, B, in_channels, HW,
+                       dtype, relu, stream);
 }
