@@ -48,6 +48,15 @@ DTYPES = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
 D, LEVELS, RADIUS = 256, 4, 4
 
 
+def note(msg):
+    """Progress line on stderr (RC_BENCH_VERBOSE=1): the JSON line on stdout stays the only stdout output."""
+    if os.environ.get("RC_BENCH_VERBOSE"):
+        print(f"[bench rank {os.environ.get('RANK', '0')} +{time.perf_counter() - _T0:.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
 def synthetic_coords(B, H, W, seed=1234, adversarial=False):
     """SURVEY 8(d) lookup coordinates: x = w - disp with disp piecewise smooth in [0, W/2] (a bilinearly
     upsampled 8x8 grid of U(0, W/3) plus U(-0.5, 0.5) noise), or i.i.d. U(0, W) for the adversarial case;
@@ -492,35 +501,71 @@ def refine_loop(step, cfg, device, reps=3, capture=True, baseline=True):
     return out
 
 
-def refine_train_step(step, cfg, device, reps=2):
+def refine_train_step(step, cfg, device, reps=2, dist=None):
     """A training step of everything after the encoders (SceneFlow shape): refinement loop in training mode
     (a prediction per iteration), sequence loss, backward down to the feature maps and the update block's
     parameters -- this package's operators against the same step in torch ops (reference-style loss included).
-    Wall clock, synchronised; random-init weights, synthetic context tensors and ground truth."""
+    Wall clock, synchronised; random-init weights, synthetic context tensors and ground truth.
+
+    With more than one rank (BASELINE config 3: RCCL gradient all-reduce at 1/2/4/8 GPUs) every rank runs the step
+    on its own batch shard with the update block wrapped in DistributedDataParallel (one process per GPU, backend
+    "nccl" = RCCL, instead of the reference's nn.DataParallel, train_stereo.py:137), and the loss is normalised
+    over the GLOBAL batch's valid pixels (train_stereo.py:58) through two scalar all-reduces
+    (raft_stereo_amd.global_batch_loss).  The torch-ops leg is single-rank only."""
     from argparse import Namespace
     import raft_stereo_amd as R
     B, H, W = cfg["batch"], cfg["H"], cfg["W"]
     dt = DTYPES[cfg["dtype"]]
     amp = dt != torch.float32
+    world = dist.get_world_size() if dist is not None else 1
     args = Namespace(hidden_dims=[128] * 3, corr_levels=LEVELS, corr_radius=RADIUS, n_downsample=2,
                      slow_fast_gru=False, n_gru_layers=3, mixed_precision=amp)
-    g = torch.Generator(device=device).manual_seed(6)
+    g = torch.Generator(device=device).manual_seed(6)          # same weights on every rank
     blk = R.BasicMultiUpdateBlockHip(args, hidden_dims=args.hidden_dims).to(device)
+    for p in blk.parameters():                                  # (nn init uses the global RNG: make it rank-independent)
+        p.data.copy_(torch.randn(p.shape, generator=g, device=device) * 0.05)
+    g = torch.Generator(device=device).manual_seed(60 + (dist.get_rank() if dist is not None else 0))
     sizes = [(H, W), ((H + 1) // 2, (W + 1) // 2), ((H + 3) // 4, (W + 3) // 4)]
     net = [torch.tanh(torch.randn((B, 128, h, w), generator=g, device=device)).to(dt) for h, w in sizes]
     inp = [list(torch.randn((B, 384, h, w), generator=g, device=device).to(dt).split(128, dim=1)) for h, w in sizes]
     gt = -torch.rand((B, 1, 4 * H, 4 * W), generator=g, device=device) * 50
     valid = (torch.rand((B, 4 * H, 4 * W), generator=g, device=device) > 0.1).float()
     iters = cfg["iters"]
+    class Refiner(torch.nn.Module):
+        """The trainable module of the step: the whole refinement loop as ONE forward, so that
+        DistributedDataParallel sees one forward and one backward per step."""
+
+        def __init__(self, block):
+            super().__init__()
+            self.block = block
+
+        def forward(self, corr_fn):
+            return R.refine_disparity(self.block, corr_fn, net, inp, args, iters=iters, test_mode=False)
+
+    model = Refiner(blk)
+    if world > 1:
+        from torch.nn.parallel import DistributedDataParallel
+        # the default 25 MB buckets, all-reduced while the backward pass is still running.  (Gradients are
+        # copied into the buckets: with gradient_as_bucket_view=True the second step's backward pass stalled in
+        # the 2-rank rehearsal.)
+        model = DistributedDataParallel(model, device_ids=[device.index], gradient_as_bucket_view=False)
+        note("update block wrapped in DistributedDataParallel")
+        if os.environ.get("RC_BENCH_VERBOSE"):
+            import faulthandler
+            faulthandler.dump_traceback_later(100, exit=False)
+    count_local = int(((valid >= 0.5) & (gt[:, 0].abs() < 700)).sum().item())
 
     def ours():
         blk.zero_grad(set_to_none=True)
         step.f1.grad = step.f2.grad = None
         corr_fn = step.cls(step.f1, step.f2, num_levels=LEVELS, radius=RADIUS)
-        preds = R.refine_disparity(blk, corr_fn, net, inp, args, iters=iters, test_mode=False)
+        preds = model(corr_fn)
         loss, _ = R.sequence_loss_hip(preds, gt, valid)
-        loss.backward()
-        return loss
+        note("forward done")
+        loss_bwd, loss_global = R.global_batch_loss(loss, count_local)     # identity with one rank
+        loss_bwd.backward()
+        note("backward done")
+        return loss_global
 
     def torch_ops():
         blk.zero_grad(set_to_none=True)
@@ -539,6 +584,8 @@ def refine_train_step(step, cfg, device, reps=2):
     def wall(fn):
         fn()
         torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
         t0 = time.perf_counter()
         for _ in range(reps):
             last = fn()
@@ -548,12 +595,33 @@ def refine_train_step(step, cfg, device, reps=2):
     torch.cuda.reset_peak_memory_stats(device)
     t_ours, l_ours = wall(ours)
     peak_ours = torch.cuda.max_memory_allocated(device) / 2 ** 30
+    out = dict(refine_train_step_ms=round(t_ours, 1), refine_train_loss=round(l_ours, 4),
+               refine_train_peak_gib=round(peak_ours, 2))
+    if world > 1:
+        t = torch.tensor([t_ours], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        seen = torch.ones(1, device=device)
+        dist.all_reduce(seen)
+        # every rank holds the same averaged gradients after the step: compare a checksum across ranks
+        chk = torch.stack([p.grad.double().sum() for p in blk.parameters() if p.grad is not None]).sum().reshape(1)
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        grad_bytes = sum(p.numel() * p.element_size() for p in blk.parameters() if p.requires_grad)
+        out.update(refine_train_step_ms=round(float(t.item()), 1), n_ranks_seen=int(seen.item()),
+                   allreduce_bytes=int(grad_bytes + 2 * 8),
+                   allreduce_what="DistributedDataParallel gradient buckets of the update block (fp32) + 2 scalars "
+                                  "(valid-pixel count, L1 numerator) per step",
+                   refine_train_global_batch=B * world,
+                   refine_train_grads_identical_across_ranks=bool(abs(float(hi.item()) - float(lo.item())) <=
+                                                                  1e-9 * max(1.0, abs(float(hi.item())))))
+        return out
     torch.cuda.reset_peak_memory_stats(device)
     t_torch, l_torch = wall(torch_ops)
     peak_torch = torch.cuda.max_memory_allocated(device) / 2 ** 30
-    return dict(refine_train_step_ms=round(t_ours, 1), refine_train_step_torch_ops_ms=round(t_torch, 1),
-                refine_train_loss=round(l_ours, 4), refine_train_loss_torch_ops=round(l_torch, 4),
-                refine_train_peak_gib=round(peak_ours, 2), refine_train_peak_gib_torch_ops=round(peak_torch, 2))
+    out.update(refine_train_step_torch_ops_ms=round(t_torch, 1), refine_train_loss_torch_ops=round(l_torch, 4),
+               refine_train_peak_gib_torch_ops=round(peak_torch, 2))
+    return out
 
 
 def hbm_resident_lookup(cfg, device, seed, batch=64, passes=3):
@@ -648,9 +716,24 @@ def main():
     ap.add_argument("--loop-only", action="store_true",
                     help="after the timed region run only the library's refine loop (no torch-ops leg, no side metrics)")
     ap.add_argument("--adversarial", action="store_true", help="i.i.d. uniform disparity (worst-case gather)")
+    ap.add_argument("--profile", action="store_true",
+                    help="profiler runs: no CPU baseline, no refinement-loop legs, no 64-pair leg (one instantiation "
+                         "of each kernel at one size per run)")
+    ap.add_argument("--debug-leg", choices=["loop_eager", "graph_step", "loop_capture"], default=None,
+                    help="after the timed region run exactly one side leg (to bisect a fault under a profiler)")
     args = ap.parse_args()
+    if args.profile:
+        args.no_cpu_baseline = args.no_refine_loop = True
+    if args.miopen_find and WORKLOADS[args.workload]["train"]:
+        # MIOpen's exhaustive search over backward-data / backward-weight solvers of every convolution shape ran
+        # past three silent minutes on the first training step (round 1): refuse instead of looking hung
+        raise SystemExit("--miopen-find is for the inference workloads; refusing it with --workload sceneflow_train")
     if args.miopen_find:
         torch.backends.cudnn.benchmark = True
+    # HIP graph capture is kept out of profiler runs by construction: under rocprofv3 counter collection the
+    # capture of the refinement loop aborted the process ("profiler fault")
+    profiler = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or \
+        "rocprofiler" in os.environ.get("LD_PRELOAD", "")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -660,13 +743,19 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)     # (a rehearsal may put several ranks on one GPU)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        # "nccl" is RCCL on ROCm; RC_BENCH_BACKEND=gloo only to rehearse the multi-rank path on a one-GPU box
+        backend = os.environ.get("RC_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     cfg = dict(WORKLOADS[args.workload])
     if args.batch:
@@ -699,6 +788,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    note("timed region done")
     cnt = algorithmic_counts(cfg)
     pairs_total = cfg["batch"] * world * args.steps
     value = pairs_total / elapsed
@@ -732,7 +822,15 @@ def main():
     if cfg["train"]:
         extra.update(backward_ms=round(float(np.median(step.bwd_ms)), 4))
 
-    if args.loop_only:
+    if args.debug_leg:
+        if args.debug_leg == "loop_eager":
+            extra.update(refine_loop(step, cfg, device, capture=False, baseline=False))
+        elif args.debug_leg == "graph_step":
+            extra.update(hip_graph_step(step))
+        else:
+            extra.update(refine_loop(step, cfg, device, capture=True, baseline=True))
+        args.loop_only = True      # nothing else
+    elif args.loop_only:
         if rank == 0 and not cfg["train"]:
             extra.update(refine_loop(step, cfg, device, capture=False, baseline=False))
     elif not is_alt and not cfg["train"] and rank == 0:
@@ -741,12 +839,18 @@ def main():
         extra.update(update_ops(cfg, device))              # side metrics, after the timed region
     if (not args.loop_only and not cfg["train"] and rank == 0 and cfg["H"] * cfg["W"] * cfg["batch"] <= 300000
             and not args.no_refine_loop):
-        extra.update(refine_loop(step, cfg, device, capture=world == 1))
-    if cfg["train"] and rank == 0 and not args.no_refine_loop and not args.loop_only:
-        extra.update(refine_train_step(step, cfg, device))
-    if not cfg["train"] and world == 1 and not args.loop_only:       # side metric; kept out of multi-rank runs (no capture beside RCCL)
-        extra.update(hip_graph_step(step))
-    if args.workload == "kitti" and not args.batch and not args.dtype and rank == 0 and not args.loop_only:
+        extra.update(refine_loop(step, cfg, device, capture=world == 1 and not profiler))
+    if cfg["train"] and not args.no_refine_loop and not args.loop_only and (rank == 0 or world > 1):
+        # config 3's gradient sync: with several ranks every rank takes part (DDP over RCCL)
+        note("side legs done; training step")
+        extra.update(refine_train_step(step, cfg, device, dist=dist))
+        note("training step done")
+    if not cfg["train"] and world == 1 and not args.loop_only and not profiler:
+        extra.update(hip_graph_step(step))       # side metric; kept out of multi-rank runs (no capture beside RCCL)
+    if profiler:
+        extra["profiler_attached"] = True
+    if (args.workload == "kitti" and not args.batch and not args.dtype and rank == 0 and not args.loop_only
+            and not args.profile):
         # the same kernel with nothing left in the Infinity Cache between lookups (after the timed region)
         extra["roofline_hbm_resident"] = hbm_resident_lookup(cfg, device, 1234 + rank)
         extra["lookup_frac_hbm_resident"] = extra["roofline_hbm_resident"]["frac"]

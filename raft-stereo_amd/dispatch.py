@@ -49,3 +49,28 @@ def shard_rows(height, world_size, rank):
     """Row-slab [lo, hi) of the feature maps for one rank: 1-D correlation never crosses image
     rows (core/corr.py:120, sampler_kernel.cu:50), so slabs need no halo and no exchange."""
     return shard_pairs(height, world_size, rank)
+
+
+def global_batch_loss(loss_local, count_local, group=None):
+    """Training across ranks (one process per GPU, DistributedDataParallel over RCCL instead of the reference's
+    nn.DataParallel, train_stereo.py:137): the reference computes sequence_loss on the gathered GLOBAL batch, a mean
+    over all its valid pixels (train_stereo.py:58, :189), so ranks with different numbers of valid pixels must not be
+    averaged with equal weight.  Given this rank's loss (a mean over its own `count_local` valid pixels) this
+    all-reduces the pixel count and the L1 numerator (two scalars) and returns
+
+        loss_for_backward  = loss_local * count_local / count_global * world_size
+                             (DDP averages the ranks' gradients, i.e. divides by world_size again, so the averaged
+                             gradient is exactly the gradient of the global-batch loss)
+        loss_global        = sum over ranks of loss_local * count_local / count_global   (detached; for logging)
+
+    With one rank (or torch.distributed not initialised) it returns the loss unchanged."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return loss_local, loss_local.detach()
+    world = dist.get_world_size(group)
+    cnt = torch.tensor([float(count_local)], dtype=torch.float64, device=loss_local.device)
+    dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
+    share = float(count_local) / max(float(cnt.item()), 1.0)
+    num = (loss_local.detach().double() * share).reshape(1).clone()
+    dist.all_reduce(num, op=dist.ReduceOp.SUM, group=group)
+    return loss_local * (share * world), num[0].to(loss_local.dtype)

@@ -30,8 +30,9 @@ def refine_disparity(update_block, corr_fn, net_list, inp_list, args, iters=12, 
     coords1 = coords0.clone() if flow_init is None else coords0 + flow_init
     # reg_hip + this package's update block: the lookup is fused with the motion encoder's first layer, in test
     # mode and in training (the backward recomputes the lookup instead of keeping 36 channels per iteration)
-    fuse = isinstance(update_block, BasicMultiUpdateBlockHip) and hasattr(corr_fn, "lookup_convc1") \
-        and corr_fn.radius <= 7
+    # (a DistributedDataParallel wrapper keeps the block under .module)
+    fuse = isinstance(getattr(update_block, "module", update_block), BasicMultiUpdateBlockHip) \
+        and hasattr(corr_fn, "lookup_convc1") and corr_fn.radius <= 7
     net_list = list(net_list)
     predictions, flow_up = [], None
     for itr in range(iters):

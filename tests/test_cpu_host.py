@@ -153,6 +153,75 @@ def test_two_rank_gloo_sharding(tmp_path):
     assert res.stdout.count("ok") == 2
 
 
+DDP_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["RC_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+from torch.nn.parallel import DistributedDataParallel as DDP
+import raft_stereo_amd as R
+from oracle import update_oracle as U
+dist.init_process_group("gloo")
+rank, ws = dist.get_rank(), dist.get_world_size()
+torch.manual_seed(0)
+N, H, W, n_pred = 4, 6, 10, 3
+net = torch.nn.Sequential(torch.nn.Conv2d(2, 5, 3, padding=1), torch.nn.Tanh(), torch.nn.Conv2d(5, n_pred, 3, padding=1))
+g = torch.Generator().manual_seed(1)
+x = torch.randn(N, 2, H, W, generator=g)
+gt = torch.randn(N, 1, H, W, generator=g) * 3
+valid = (torch.rand(N, H, W, generator=g) > 0.3).float()
+valid[0] = 0.0                       # the ranks see very different numbers of valid pixels
+valid[1, :, :3] = 0.0
+
+def loss_of(model, xs, gts, valids):
+    """sequence_loss in torch ops (train_stereo.py:35-70): gamma-weighted means of |pred - gt| over valid pixels"""
+    preds = model(xs)
+    mask = ((valids >= 0.5) & (gts[:, 0].abs() < 700)).unsqueeze(1)
+    gamma = 0.9 ** (15 / (n_pred - 1))
+    tot = 0.0
+    for i in range(n_pred):
+        tot = tot + gamma ** (n_pred - i - 1) * (preds[:, i:i + 1] - gts).abs()[mask].mean()
+    return tot, int(mask.sum()), [preds[:, i:i + 1] for i in range(n_pred)]
+
+# one rank, the global batch (what nn.DataParallel + the loss on the gathered batch computes, train_stereo.py:186-193)
+ref_loss, _, ref_preds = loss_of(net, x, gt, valid)
+ref_grads = torch.autograd.grad(ref_loss, list(net.parameters()))
+# ... pinned on the numpy oracle of sequence_loss
+o_loss, _, _ = U.sequence_loss([p.detach().numpy() for p in ref_preds], gt.numpy(), valid.numpy())
+assert abs(float(ref_loss) - float(o_loss)) < 1e-5 * abs(float(o_loss))
+
+# two ranks, half a batch each, DDP + the two scalar all-reduces
+lo, hi = R.shard_pairs(N, ws, rank)
+ddp = DDP(net)
+loss, cnt, _ = loss_of(ddp, x[lo:hi], gt[lo:hi], valid[lo:hi])
+loss = loss if cnt else loss * 0 + sum(p.sum() for p in net.parameters()) * 0     # a rank without valid pixels: nan mean
+loss_bwd, loss_global = R.global_batch_loss(torch.nan_to_num(loss), cnt)
+loss_bwd.backward()
+assert abs(float(loss_global) - float(ref_loss)) < 1e-5 * abs(float(ref_loss)), (float(loss_global), float(ref_loss))
+for p, gr in zip(net.parameters(), ref_grads):
+    assert torch.allclose(p.grad, gr, rtol=1e-4, atol=1e-6), float((p.grad - gr).abs().max())
+# per-rank means averaged with equal weight would NOT be the reference's loss
+naive = torch.tensor([float(torch.nan_to_num(loss))]); dist.all_reduce(naive); naive /= ws
+assert abs(float(naive) - float(ref_loss)) > 1e-3
+seen = torch.ones(1); dist.all_reduce(seen)
+assert int(seen.item()) == ws
+dist.barrier()
+print("rank", rank, "ddp ok")
+'''
+
+
+def test_two_rank_gloo_ddp_loss_and_gradient_parity(tmp_path):
+    """SURVEY 4 / 8(e): DDP gradient parity, 1 rank on the global batch against 2 ranks on half batches with the
+    valid-pixel-count normalisation of train_stereo.py:58 (global_batch_loss)."""
+    script = tmp_path / "ddp_worker.py"
+    script.write_text(DDP_WORKER)
+    env = dict(os.environ, RC_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29537", str(script)],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    assert res.stdout.count("ddp ok") == 2
+
+
 def test_bench_input_generator_matches_the_oracles():
     """bench.py carries its own copy of the synthetic-coordinate generator (only its cpu_baseline leg may touch
     oracle/); both copies must produce the same workload."""

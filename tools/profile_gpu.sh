@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 args=("$@")
 run() {  # name, rocprof options...
   local name=$1; shift
-  timeout -s KILL 120 rocprofv3 "$@" -d "$out/$name" -o "$name" --output-format csv -- python3 bench.py "${args[@]}" --no-cpu-baseline --no-refine-loop > "$out/$name.log" 2>&1 || { echo "pass $name failed"; tail -5 "$out/$name.log"; return 1; }
+  timeout -s KILL 120 rocprofv3 "$@" -d "$out/$name" -o "$name" --output-format csv -- python3 bench.py "${args[@]}" --profile > "$out/$name.log" 2>&1 || { echo "pass $name failed"; tail -5 "$out/$name.log"; return 1; }
   echo "pass $name ok"
 }
 run kt --kernel-trace --stats &&
