@@ -122,6 +122,8 @@ class _BuildFn(torch.autograd.Function):
                 sum1 = sum2 = None
                 for part in chunks:
                     n = len(part)
+                    if len({c.shape[1] for c, _ in part}) != 1:     # one channel count per fused call
+                        part = [(c[:, :1].contiguous(), g) for c, g in part]
                     cl = (ctypes.c_void_p * n)(*[c.data_ptr() for c, _ in part])
                     gl = (ctypes.c_void_p * n)(*[g.data_ptr() for _, g in part])
                     check(lib.rc_lookup_bwd_dense(cl, gl, n, part[0][0].shape[1], dense.data_ptr(), lay, block.D,
@@ -155,7 +157,7 @@ class _LookupFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, token, coords, block):
         ctx.block = block
-        ctx.coords = coords       # detached fp32 (see _check_coords): kept as is, no saved-tensor bookkeeping
+        ctx.save_for_backward(coords)    # saved, not stashed: an in-place edit of coords before backward raises
         return block._lookup(coords)
 
     @staticmethod
@@ -164,7 +166,8 @@ class _LookupFn(torch.autograd.Function):
         # takes all (coords, grad_out) pairs in one fused call
         if grad_out.dtype is not torch.float32 or not grad_out.is_contiguous():
             grad_out = grad_out.float().contiguous()                              # core/corr.py:27
-        ctx.block._pending.append((ctx.coords, grad_out))
+        coords, = ctx.saved_tensors
+        ctx.block._pending.append((coords, grad_out))
         return None, None, None     # autograd still runs the build's backward once all lookups have
 
 
@@ -176,17 +179,17 @@ class _LookupConvc1Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, token, coords, weight, bias, block, relu):
         act = block._lookup_convc1(coords, weight, bias, relu)
-        ctx.block, ctx.coords, ctx.relu, ctx.has_token = block, coords, relu, token is not None
-        ctx.save_for_backward(act, weight, bias)
+        ctx.block, ctx.relu, ctx.has_token = block, relu, token is not None
+        ctx.save_for_backward(act, weight, bias, coords)
         return act
 
     @staticmethod
     def backward(ctx, grad_act):
-        act, weight, bias = ctx.saved_tensors
+        act, weight, bias, coords = ctx.saved_tensors
         block = ctx.block
         K = block.num_levels * (2 * block.radius + 1)
         dev = block.device
-        corr = block._lookup(ctx.coords)                      # recomputed: the forward never stored it
+        corr = block._lookup(coords)                          # recomputed: the forward never stored it
         g = grad_act.to(act.dtype).contiguous()
         w32 = weight.detach().reshape(_lib.RC_CONVC1_OUT, K).float().contiguous()
         with torch.cuda.device(dev):
@@ -199,7 +202,7 @@ class _LookupConvc1Fn(torch.autograd.Function):
                                     block.H * block.W1, block.vol_dtype, int(ctx.relu), _stream(dev)),
                   "rc_convc1_bwd")
         if ctx.has_token:
-            block._pending.append((ctx.coords, grad_corr))    # taken by the build's backward
+            block._pending.append((coords, grad_corr))        # taken by the build's backward
         return None, None, gw.view(weight.shape).to(weight.dtype), gb.view(bias.shape).to(bias.dtype), None, None
 
 

@@ -197,13 +197,25 @@ class ConvGRUHip(nn.Module):
         self.convq = nn.Conv2d(hidden_dim + input_dim, hidden_dim, kernel_size, padding=kernel_size // 2)
 
     def _stacked(self, dt):
-        """convz and convr as one convolution: stacked weight and bias, cached while the parameters stand still."""
-        key = (dt, self.convz.weight._version, self.convr.weight._version, self.convz.bias._version,
-               self.convr.bias._version, self.convz.weight.data_ptr(), self.convr.weight.data_ptr())
-        if getattr(self, "_zr_key", None) != key:
+        """convz and convr as one convolution: stacked weight and bias, cached while the parameters stand still.
+        When they change (load_state_dict, an optimizer step) the cached buffers are refreshed IN PLACE, so a HIP
+        graph captured over the inference path keeps reading current values on replay; tensors whose version
+        counter cannot be read (inference-mode tensors) are re-stacked on every call."""
+        params = (self.convz.weight, self.convr.weight, self.convz.bias, self.convr.bias)
+        try:
+            key = (dt,) + tuple(p._version for p in params) + tuple(p.data_ptr() for p in params)
+        except RuntimeError:
+            key = None
+        if key is None or getattr(self, "_zr_key", None) != key:
             with torch.no_grad():
-                self._zr_w = torch.cat([self.convz.weight, self.convr.weight], dim=0).to(dt)
-                self._zr_b = torch.cat([self.convz.bias, self.convr.bias], dim=0).to(dt)
+                w = torch.cat([self.convz.weight, self.convr.weight], dim=0).to(dt)
+                b = torch.cat([self.convz.bias, self.convr.bias], dim=0).to(dt)
+                old = getattr(self, "_zr_w", None)
+                if old is not None and old.shape == w.shape and old.dtype == w.dtype and old.device == w.device:
+                    self._zr_w.copy_(w)
+                    self._zr_b.copy_(b)
+                else:
+                    self._zr_w, self._zr_b = w, b
             self._zr_key = key
         return self._zr_w, self._zr_b
 
@@ -219,8 +231,10 @@ class ConvGRUHip(nn.Module):
         # features carry the fp32 flow, update.py:85 -- no longer drags the whole buffer through fp32)
         hx = torch.cat([t.to(dt) for t in (h, *x_list)], dim=1)
         h, cz, cr, cq = h.to(dt).contiguous(), cz.to(dt), cr.to(dt), cq.to(dt)
+        # any trainable parameter (not only convz: a fine-tune may freeze some of them) or input takes the
+        # autograd route
         train = torch.is_grad_enabled() and (hx.requires_grad or cr.requires_grad or cz.requires_grad
-                                             or cq.requires_grad or self.convz.weight.requires_grad)
+                                             or cq.requires_grad or any(p.requires_grad for p in self.parameters()))
         if train:
             zr = nn.functional.conv2d(hx, torch.cat([self.convz.weight, self.convr.weight], dim=0).to(dt),
                                       torch.cat([self.convz.bias, self.convr.bias], dim=0).to(dt),

@@ -21,10 +21,10 @@ def _run(lib, check, fn_static, B, K, H, W, dtype, rc_dtype, relu, seed):
         gw = torch.full((64, K), float("nan"), device="cuda")
         gb = torch.full((64,), float("nan"), device="cuda")
         if static:
-            before = torch.cuda.memory_allocated()
+            before = torch.cuda.memory_stats()["allocation.all.allocated"]     # allocation COUNT (frees by the gc do not move it)
             check(fn_static(corr.data_ptr(), act.data_ptr(), gact.data_ptr(), weight.data_ptr(), gcorr.data_ptr(),
                             gw.data_ptr(), gb.data_ptr(), B, K, H * W, rc_dtype, relu, st), "rc_convc1_bwd_static")
-            assert torch.cuda.memory_allocated() == before
+            assert torch.cuda.memory_stats()["allocation.all.allocated"] == before
         else:
             work = torch.full((int(lib.rc_convc1_bwd_work_bytes()),), 0x7f, dtype=torch.uint8, device="cuda")
             check(lib.rc_convc1_bwd(corr.data_ptr(), act.data_ptr(), gact.data_ptr(), weight.data_ptr(),
