@@ -5,17 +5,19 @@
 // (`cor = F.relu(self.convc1(corr))`) of the reference: the L*(2r+1)-channel fp32 tensor between
 // the two (144 B written + 144 B read back per pixel and iteration) never exists.
 //
-// A wave owns 64 consecutive pixels of one image row.  Gather: lane = pixel, exactly the plain lookup
-// (two runs of 16-byte blocks per pixel, levels 1 and 3 derived in registers; every load instruction
-// of the wave reads long contiguous runs).  The taps are rounded to the pyramid's type and packed,
-// K slot = 16 level + tap.  A 4x4 transpose over the lane rows (v_permlane16/32_swap) per packed
-// dword then gives lane (g, li) the slots of LEVEL g of pixel 16 s + li in register s: the
-// B-operand layout of the MFMA (column = pixel, K = 8 (lane / 16) + j within a 32-slot step), so
-//     C[out channel][pixel] += Wp[out channel][K] * taps[K][pixel],   K = 4 levels x 16 tap slots
-// (unused slots carry zero weights and zero taps) runs once per 16 pixels.  Weights come
-// pre-arranged in fragment order (rc_convc1_pack); the accumulators start from the bias.  A second
-// 4x4 transpose leaves lane = pixel again, so every output channel plane is written in one
-// contiguous run per wave.
+// A wave owns 64 consecutive pixels of the flattened image.  Gather: one pixel per lane, exactly the plain
+// lookup (two runs of 16-byte blocks per pixel, levels 1 and 3 derived in registers).  The taps are rounded to
+// the pyramid's type and packed, K slot = 16 level + tap.  A 4x4 transpose over the lane rows
+// (v_permlane16/32_swap) per packed dword then gives lane (g, li) the slots of LEVEL g of the pixel that lane
+// (s, li) gathered, in register s: the A-operand layout of the MFMA (row = pixel, K = 8 (lane / 16) + j within a
+// 32-slot step), so
+//     C[pixel][out channel] += taps[pixel][K] * Wp[K][out channel],   K = 4 levels x 16 tap slots
+// (unused slots carry zero weights and zero taps) runs once per 16 pixels.  Weights come pre-arranged in
+// fragment order (rc_convc1_pack); the accumulators start from the bias.  MFMA rows are pixels, so a lane ends
+// up with 4 pixels of one output channel per pass; the lane -> pixel assignment of the gather,
+//     pixel = 32 (s / 2) + 8 (li / 4) + 4 (s % 2) + li % 4          (s = lane / 16, li = lane % 16),
+// makes those 4 x 4 pixels of a lane 16 consecutive ones, so the activations leave as 16-byte stores, 64
+// contiguous bytes per channel plane and instruction, with no second transpose.
 //   16-bit pyramid: taps rounded to the pyramid's type, v_mfma_f32_16x16x32 (f32 accumulate),
 //                   output in that type (what autocast makes of convc1);
 //   f32 pyramid:    v_mfma_f32_16x16x4_f32, f32 output.
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __r
                                                                    const VT* __restrict__ wpack,
                                                                    const float* __restrict__ bias,
                                                                    VT* __restrict__ out, int chunks_per_image,
-                                                                   int n_items, int relu) {
+                                                                   int n_items, int relu, int nts) {
   constexpr bool IS16 = sizeof(VT) == 2;
   using PF = pair_fetch<VT, R, MODE>;
   using SF = single_fetch<VT, R, MODE>;
@@ -127,15 +129,17 @@ __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __r
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int item = blockIdx.x * (FC_THREADS / 64) + wave;  // (image, 64-pixel chunk), wave-uniform
   if (item >= n_items) return;
-  const px_item it = locate_item(item, chunks_per_image, lay.H, lay.W1, lane);
+  // the lane's pixel inside the chunk (see the header): rows of the later MFMA land 16 consecutive pixels per lane
+  const int poff = 32 * (lane >> 5) + 8 * ((lane & 15) >> 2) + 4 * ((lane >> 4) & 1) + (lane & 3);
+  const px_item it = locate_item(item, chunks_per_image, lay.H, lay.W1, poff);
   const int b = it.b, h = it.h, w1g = it.w1;  // lanes past the end of the image repeat its last pixel (never stored)
   const int64_t HW = (int64_t)lay.H * lay.W1;
   const int g = lane >> 4;
   const uint32_t blk_bytes = (uint32_t)lay.pitch * 16u;
   const int L = lay.L;
 
-  // ---- phase 1: the plain lookup's gather, lane = pixel: taps of every level in registers
-  const float x = (coords + uniform(((int64_t)b * coords_channels) * HW))[min(it.p0 + lane, (int)HW - 1)];
+  // ---- phase 1: the plain lookup's gather, one pixel per lane: taps of every level in registers
+  const float x = (coords + uniform(((int64_t)b * coords_channels) * HW))[min(it.p0 + poff, (int)HW - 1)];
   float tap[RC_MAX_LEVELS][NT];
 #pragma unroll
   for (int i = 0; i < RC_MAX_LEVELS; ++i)
@@ -177,10 +181,11 @@ __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __r
     }
   }
 
-  // weights (A operand: row = out channel 16 t + li, K slots of level g) and bias (C rows 4 g + r)
+  // weights (B operand: column = out channel 16 t + li, K slots of level g) and bias (C column li)
+  const int li = lane & 15;
   uint4 wa16[4][2];
   float wa32[4][NT];
-  f4v acc[4][4];  // [pass][t]
+  float bv[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     if constexpr (IS16) {
@@ -190,14 +195,18 @@ __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __r
 #pragma unroll
       for (int e = 0; e < NT; ++e) wa32[t][e] = reinterpret_cast<const float*>(wpack)[(t * 16 + e) * 64 + lane];
     }
-    const f4v bv = *reinterpret_cast<const f4v*>(bias + 16 * t + 4 * g);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) acc[s][t] = bv;
+    bv[t] = bias[16 * t + li];
   }
+
+  f4v acc[4][4];  // [pass][t]
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc[s][t] = (f4v){bv[t], bv[t], bv[t], bv[t]};
 
   // ---- phase 2: lane rows <-> levels, then the 1x1 convolution on the matrix cores
   if constexpr (IS16) {
-    uint32_t bq[4][8];  // [pass s][dword of the level's 16 slots] of lane (g, li): level g of pixel 16 s + li
+    uint32_t aq[4][8];  // [pass s][dword of the level's 16 slots] of lane (g, li): level g of the pixel of lane (s, li)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       if (j < NDW) {
@@ -206,20 +215,20 @@ __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __r
         for (int i = 0; i < 4; ++i) r[i] = pack2<VT>(tap[i][2 * j], 2 * j + 1 < NT ? tap[i][2 * j + 1] : 0.f);
         transpose_rows(r);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) bq[s][j] = r[s];
+        for (int s = 0; s < 4; ++s) aq[s][j] = r[s];
       } else {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) bq[s][j] = 0u;
+        for (int s = 0; s < 4; ++s) aq[s][j] = 0u;
       }
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const uint4 b0 = make_uint4(bq[s][0], bq[s][1], bq[s][2], bq[s][3]);
-      const uint4 b1 = make_uint4(bq[s][4], bq[s][5], bq[s][6], bq[s][7]);
+      const uint4 a0 = make_uint4(aq[s][0], aq[s][1], aq[s][2], aq[s][3]);
+      const uint4 a1 = make_uint4(aq[s][4], aq[s][5], aq[s][6], aq[s][7]);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        acc[s][t] = mfma16<VT>(wa16[t][0], b0, acc[s][t]);
-        if (NT > 8) acc[s][t] = mfma16<VT>(wa16[t][1], b1, acc[s][t]);
+        acc[s][t] = mfma16<VT>(a0, wa16[t][0], acc[s][t]);
+        if (NT > 8) acc[s][t] = mfma16<VT>(a1, wa16[t][1], acc[s][t]);
       }
     }
   } else {
@@ -228,58 +237,56 @@ __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __r
       uint32_t r[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) r[i] = __float_as_uint(tap[i][e]);
-      transpose_rows(r);  // r[s] of lane (g, li): tap e of level g of pixel 16 s + li
+      transpose_rows(r);  // r[s] of lane (g, li): tap e of level g of the pixel of lane (s, li)
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int t = 0; t < 4; ++t)
-          acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa32[t][e], __uint_as_float(r[s]), acc[s][t], 0, 0, 0);
+          acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(r[s]), wa32[t][e], acc[s][t], 0, 0, 0);
     }
   }
 
-  // ---- phase 3: lane rows <-> passes, so that lane = pixel; activation; one run per channel plane
-  const int pix = it.p0 + lane;  // flattened pixel of this lane
-  VT* orow = out + uniform(((int64_t)b * FC_OUT) * HW + it.p0);
-  // 16-bit outputs leave as dwords when rows start on even pixels: neighbouring lanes trade one
-  // channel each (even lanes keep the first channel of a pair for pixels (l, l+1), odd lanes the
-  // second for (l-1, l)), so one store instruction writes two 128-byte runs
-  const bool pairs = IS16 && (HW & 1) == 0 && (reinterpret_cast<uintptr_t>(out) & 3) == 0;
-  const bool odd = lane & 1;
-  const int64_t plane_b = HW * (int64_t)sizeof(VT);
+  // ---- phase 3: activation and stores.  acc[s][t][r] = channel 16 t + li of pixel 32 (s / 2) + 8 g + 4 (s % 2) + r:
+  // per (t, s / 2) the lane holds 8 consecutive pixels of one channel plane
+  VT* obase = out + uniform(((int64_t)b * FC_OUT) * HW + it.p0);
+  const bool vec = (HW * (int64_t)sizeof(VT)) % 16 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;  // wave-uniform
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
+    const uint32_t plane = (uint32_t)(16 * t + li) * (uint32_t)HW;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float x0 = acc[0][t][r], x1 = acc[1][t][r], x2 = acc[2][t][r], x3 = acc[3][t][r];
-      swap16(x0, x1);
-      swap16(x2, x3);
-      swap32(x0, x2);
-      swap32(x1, x3);
-      float xs[4] = {x0, x1, x2, x3};  // channel 16 t + 4 s + r of pixel c0 + lane
+    for (int hs = 0; hs < 2; ++hs) {
+      float v[8];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) xs[s] = relu ? fmaxf(xs[s], 0.f) : xs[s];
-      bool stored = false;
-      if constexpr (IS16) {
-        if (pairs) {  // wave-uniform
+      for (int e = 0; e < 2; ++e)
 #pragma unroll
-          for (int p = 0; p < 2; ++p) {
-            const float a = xs[2 * p], bb = xs[2 * p + 1];  // channels ca, ca + 4
-            const int ca = 16 * t + 8 * p + r;
-            const float recv = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(odd ? a : bb),
-                                                                       0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true));
-            const uint32_t word = pack2<VT>(odd ? recv : a, odd ? bb : recv);
-            char* dst = reinterpret_cast<char*>(orow) + uniform((int64_t)ca * plane_b);
-            const uint32_t voff =
-                (odd ? (uint32_t)(4 * plane_b) : 0u) + (uint32_t)(lane & ~1) * (uint32_t)sizeof(VT);
-            if ((pix & ~1) < (int)HW) *reinterpret_cast<uint32_t*>(dst + voff) = word;
-          }
-          stored = true;
+        for (int r = 0; r < 4; ++r) {
+          const float a = acc[2 * hs + e][t][r];
+          v[4 * e + r] = relu ? fmaxf(a, 0.f) : a;
         }
-      }
-      if (!stored) {
+      const int q = 32 * hs + 8 * g;  // first of the 8 pixels, inside the chunk
+      VT* dst = obase + (plane + (uint32_t)q);
+      if (vec) {  // whole 16-byte pieces: HW is a multiple of the piece, so a piece is inside the image or outside
+        if (it.p0 + q < (int)HW) {
+          if constexpr (IS16) {
+            typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+            const u4 w = {pack2<VT>(v[0], v[1]), pack2<VT>(v[2], v[3]), pack2<VT>(v[4], v[5]), pack2<VT>(v[6], v[7])};
+            if (nts) __builtin_nontemporal_store(w, reinterpret_cast<u4*>(dst));  // wave-uniform
+            else *reinterpret_cast<u4*>(dst) = w;
+          } else {
+            const f4v w0 = {v[0], v[1], v[2], v[3]}, w1 = {v[4], v[5], v[6], v[7]};
+            if (nts) {
+              __builtin_nontemporal_store(w0, reinterpret_cast<f4v*>(dst));
+              __builtin_nontemporal_store(w1, reinterpret_cast<f4v*>(dst + 4));
+            } else {
+              *reinterpret_cast<f4v*>(dst) = w0;
+              *reinterpret_cast<f4v*>(dst + 4) = w1;
+            }
+          }
+        }
+      } else {
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-          if (pix < (int)HW) (orow + uniform((int64_t)(16 * t + 4 * s + r) * HW))[lane] = rc_from_float<VT>(xs[s]);
+        for (int e = 0; e < 8; ++e)
+          if (it.p0 + q + e < (int)HW) dst[e] = rc_from_float<VT>(v[e]);
       }
     }
   }
@@ -291,14 +298,17 @@ int launch_fused(const void* vol, rc_dev_layout d, const float* coords, int cc, 
   const int chunks = (d.H * d.W1 + 63) / 64;
   const int n_items = (int)((int64_t)d.B * chunks);
   const int blocks = (n_items + (FC_THREADS / 64) - 1) / (FC_THREADS / 64);
+  // non-temporal stores (what the plain lookup uses for outputs beyond the Infinity Cache) are slower here:
+  // this kernel's pieces are 64 bytes per channel plane and instruction (KITTI, 64 pairs: 108.6 -> 125 us)
+  const int nts = 0;
   if (mode == RC_COORD_EXACT) {
     set_row_bias(d, vt_info<VT>::RB, pair_info<vt_info<VT>::RB, R, RC_COORD_EXACT>::NW2);
     hipLaunchKernelGGL((lookup_convc1_kernel<VT, R, RC_COORD_EXACT>), dim3(blocks), dim3(FC_THREADS), 0, st,
-                       (const VT*)vol, d, coords, cc, (const VT*)wpack, bias, (VT*)out, chunks, n_items, relu);
+                       (const VT*)vol, d, coords, cc, (const VT*)wpack, bias, (VT*)out, chunks, n_items, relu, nts);
   } else {
     set_row_bias(d, vt_info<VT>::RB, pair_info<vt_info<VT>::RB, R, RC_COORD_GRIDSAMPLE>::NW2);
     hipLaunchKernelGGL((lookup_convc1_kernel<VT, R, RC_COORD_GRIDSAMPLE>), dim3(blocks), dim3(FC_THREADS), 0, st,
-                       (const VT*)vol, d, coords, cc, (const VT*)wpack, bias, (VT*)out, chunks, n_items, relu);
+                       (const VT*)vol, d, coords, cc, (const VT*)wpack, bias, (VT*)out, chunks, n_items, relu, nts);
   }
   return rc_check_launch("rc_lookup_convc1_fwd");
 }
@@ -358,6 +368,8 @@ extern "C" int rc_lookup_convc1_fwd(const void* vol, const rc_layout* lay, const
   int rc = check_common(lay, vol, coords, out, coords_channels, radius, coord_mode);
   if (rc) return rc;
   RC_REQUIRE(!lay->full, RC_EINVAL, "rc_lookup_convc1_fwd takes a forward pyramid (rc_pyramid_layout)");
+  RC_REQUIRE((int64_t)RC_CONVC1_OUT * lay->H * lay->W1 < (1ll << 29), RC_EINVAL,
+             "one image's output planes exceed the 32-bit lane offset range");
   RC_REQUIRE((uintptr_t)packed_weight % 16 == 0 && (uintptr_t)bias % 16 == 0, RC_EINVAL,
              "packed weights and bias must be 16-byte aligned");
   const rc_dev_layout d = rc_to_dev(lay);
