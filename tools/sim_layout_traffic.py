@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Line-level traffic model of candidate pyramid layouts (CPU only; quoted in DESIGN.md section 10).
+
+For the bench's own lookup coordinates it counts, per image row and level, the distinct 128-byte lines a
+lookup touches when a line holds P pixels x E consecutive entries (P * E = 64 two-byte elements), for
+  cur   the group-skewed layout of include/raftcorr.h   (block row = w2 / E - (w1 >> i) / E)
+  disp  a disparity-major layout                         (block row = (w2 - (w1 >> i)) / E)
+with one window per level (`separate`) or one run per level pair, levels (0,1) and (2,3) (`merged`: what the
+library does since round 2).  Output: bytes per pixel and lookup.
+
+    python tools/sim_layout_traffic.py [exact|gridsample]
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import synthetic_coords  # noqa: E402
+
+B, H, W, R = 2, 96, 312, 4
+
+
+def count(x, level, start, nw, layout, P, E):
+    Wi = W >> level
+    q = np.arange(W) >> level
+    cnt = 0
+    for b in range(x.shape[0]):
+        for h in range(H):
+            keys = []
+            for m in range(nw):
+                w2 = start[b, h] + m
+                ok = (w2 >= 0) & (w2 < Wi)
+                row = (w2 // E - q // E) if layout == "cur" else (w2 - q + 4096) // E
+                keys.append((row * 1000 + np.arange(W) // P)[ok])
+            cnt += len(np.unique(np.concatenate(keys)))
+    return cnt * 128 / (x.shape[0] * H * W)
+
+
+def run(c, name, ext):
+    nw = 2 * R + 2 + 2 * ext
+    x = c[:, 0]
+    s = [np.floor(x / 2 ** i).astype(int) - R - ext for i in range(4)]
+    for lay, P, E in [("cur", 8, 8), ("disp", 8, 8), ("disp", 16, 4), ("disp", 32, 2)]:
+        sep = [count(x, i, s[i], nw, lay, P, E) for i in range(4)]
+        m01 = count(x, 0, 2 * s[1], 2 * nw, lay, P, E)
+        m23 = count(x, 2, 2 * s[3], 2 * nw, lay, P, E)
+        print(f"{name:6s} {lay:4s} {P:2d} px x {E} entries per line: separate {[round(v, 1) for v in sep]} = "
+              f"{sum(sep):6.1f} B/px   merged (0,1) {m01:5.1f} + (2,3) {m23:5.1f} = {m01 + m23:6.1f} B/px")
+
+
+if __name__ == "__main__":
+    ext = 1 if len(sys.argv) > 1 and sys.argv[1] == "gridsample" else 0
+    c = synthetic_coords(B, H, W, seed=1234)
+    run(c, "bench", ext)
+    c0 = c.copy()
+    c0[:, 0] = np.arange(W)[None, None, :] - 20.3
+    run(c0, "const", ext)
