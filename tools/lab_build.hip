@@ -4,6 +4,10 @@
 //        tools/lab_build.hip raft-stereo_amd/csrc/build.hip raft-stereo_amd/csrc/core.hip; done
 #include "../raft-stereo_amd/csrc/rc_common.h"
 
+#ifndef RC_LAB_ABLATE
+#define RC_LAB_ABLATE 0
+#endif
+
 #include <stdlib.h>
 #include <algorithm>
 #include <vector>
