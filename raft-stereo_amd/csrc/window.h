@@ -202,8 +202,14 @@ __device__ __forceinline__ void interp_taps(const float (&v)[NW], int wbase, int
     if (__builtin_expect(__any(odd), 0)) {
 #pragma unroll
       for (int k = 0; k < NT; ++k) {
-        const float va = dlt[k] < 0 ? v[k] : (dlt[k] > 0 ? v[k + 2] : v[k + 1]);
-        const float vb = dlt[k] < 0 ? v[k + 1] : (dlt[k] > 0 ? v[k + 3] : v[k + 2]);
+        // (the operands are read into temporaries and pinned first: a select between array ELEMENTS is turned
+        // into a dynamically indexed, scratch-backed array by the compiler -- 112 bytes of scratch per lane
+        // and a third of the f32 lookup's speed when that happened)
+        float a0 = v[k], a1 = v[k + 1], a2 = v[k + 2], a3 = v[k + 3];
+        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+        const bool lt = dlt[k] < 0, gt = dlt[k] > 0;
+        const float va = lt ? a0 : (gt ? a2 : a1);
+        const float vb = lt ? a1 : (gt ? a3 : a2);
         tap[k] = va * w0[k] + vb * w1w[k];
       }
     } else {
