@@ -17,7 +17,11 @@
 // up with 4 pixels of one output channel per pass; the lane -> pixel assignment of the gather,
 //     pixel = 32 (s / 2) + 8 (li / 4) + 4 (s % 2) + li % 4          (s = lane / 16, li = lane % 16),
 // makes those 4 x 4 pixels of a lane 16 consecutive ones, so the activations leave as 16-byte stores, 64
-// contiguous bytes per channel plane and instruction, with no second transpose.
+// contiguous bytes per channel plane and instruction, with no second transpose (f32 outputs, odd sizes).
+// 16-bit outputs made of whole 16-byte pieces take one more hop, through a wave-private LDS tile
+// [channel][64 pixels]: every store instruction then writes whole 128-byte lines (8 planes x 64 pixels), which
+// is also what lets outputs beyond the Infinity Cache leave through non-temporal stores; the gather is in
+// natural order there (pixel = lane).
 //   16-bit pyramid: taps rounded to the pyramid's type, v_mfma_f32_16x16x32 (f32 accumulate),
 //                   output in that type (what autocast makes of convc1);
 //   f32 pyramid:    v_mfma_f32_16x16x4_f32, f32 output.
@@ -129,8 +133,12 @@ __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __r
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int item = blockIdx.x * (FC_THREADS / 64) + wave;  // (image, 64-pixel chunk), wave-uniform
   if (item >= n_items) return;
+  const int64_t HW_ = (int64_t)lay.H * lay.W1;
   // the lane's pixel inside the chunk (see the header): rows of the later MFMA land 16 consecutive pixels per lane
-  const int poff = 32 * (lane >> 5) + 8 * ((lane & 15) >> 2) + 4 * ((lane >> 4) & 1) + (lane & 3);
+  // (16-bit outputs in whole 16-byte pieces go through an LDS tile instead and gather in natural order)
+  const bool vec = (HW_ * (int64_t)sizeof(VT)) % 16 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;  // wave-uniform
+  const bool natural = IS16 && vec;
+  const int poff = natural ? lane : 32 * (lane >> 5) + 8 * ((lane & 15) >> 2) + 4 * ((lane >> 4) & 1) + (lane & 3);
   const px_item it = locate_item(item, chunks_per_image, lay.H, lay.W1, poff);
   const int b = it.b, h = it.h, w1g = it.w1;  // lanes past the end of the image repeat its last pixel (never stored)
   const int64_t HW = (int64_t)lay.H * lay.W1;
@@ -249,7 +257,44 @@ __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __r
   // ---- phase 3: activation and stores.  acc[s][t][r] = channel 16 t + li of pixel 32 (s / 2) + 8 g + 4 (s % 2) + r:
   // per (t, s / 2) the lane holds 8 consecutive pixels of one channel plane
   VT* obase = out + uniform(((int64_t)b * FC_OUT) * HW + it.p0);
-  const bool vec = (HW * (int64_t)sizeof(VT)) % 16 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;  // wave-uniform
+  if constexpr (IS16) {
+    if (vec) {
+      // 16-bit outputs go through a wave-private LDS tile [channel][64 pixels] (pitch 136 B: the 16 lanes of a
+      // lane row write 16 different bank pairs) so that every store instruction writes WHOLE 128-byte lines: 8
+      // channel planes x the wave's 64 pixels.  Straight from the accumulators a store covers 64 bytes of 16
+      // planes, which merges in L2 but rules out non-temporal stores for outputs beyond the Infinity Cache.
+      constexpr int PITCH = 136;
+      __shared__ __attribute__((aligned(16))) unsigned char otile[FC_THREADS / 64][FC_OUT * PITCH];
+      unsigned char* tile = otile[wave];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = relu ? fmaxf(acc[s][t][r], 0.f) : acc[s][t][r];
+          const int px = 16 * s + 4 * g;  // natural gather order: pass s, row 4 g + r is pixel 16 s + 4 g + r
+          *reinterpret_cast<uint2*>(tile + (16 * t + li) * PITCH + px * 2) =
+              make_uint2(pack2<VT>(v[0], v[1]), pack2<VT>(v[2], v[3]));
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the tile is this wave's own: no barrier
+      __builtin_amdgcn_wave_barrier();
+      typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+      const int seg = lane & 7;
+      const bool inside = it.p0 + 8 * seg < (int)HW;  // HW is a multiple of 8 here: a piece is inside or outside
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int ch = 8 * i + (lane >> 3);
+        const u4 w = *reinterpret_cast<const u4*>(tile + ch * PITCH + seg * 16);
+        u4* dst = reinterpret_cast<u4*>(obase + ((uint32_t)ch * (uint32_t)HW + (uint32_t)(8 * seg)));
+        if (inside) {
+          if (nts) __builtin_nontemporal_store(w, dst);  // wave-uniform
+          else *dst = w;
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const uint32_t plane = (uint32_t)(16 * t + li) * (uint32_t)HW;
@@ -298,9 +343,9 @@ int launch_fused(const void* vol, rc_dev_layout d, const float* coords, int cc, 
   const int chunks = (d.H * d.W1 + 63) / 64;
   const int n_items = (int)((int64_t)d.B * chunks);
   const int blocks = (n_items + (FC_THREADS / 64) - 1) / (FC_THREADS / 64);
-  // non-temporal stores (what the plain lookup uses for outputs beyond the Infinity Cache) are slower here:
-  // this kernel's pieces are 64 bytes per channel plane and instruction (KITTI, 64 pairs: 108.6 -> 125 us)
-  const int nts = 0;
+  // outputs that cannot stay in the Infinity Cache until their consumer runs leave through non-temporal stores
+  // (the same rule and threshold as the plain lookup, lookup.hip); 16-bit outputs only: their stores cover whole lines
+  const int nts = sizeof(VT) == 2 && (int64_t)d.B * FC_OUT * d.H * d.W1 * (int64_t)sizeof(VT) > (160ll << 20);
   if (mode == RC_COORD_EXACT) {
     set_row_bias(d, vt_info<VT>::RB, pair_info<vt_info<VT>::RB, R, RC_COORD_EXACT>::NW2);
     hipLaunchKernelGGL((lookup_convc1_kernel<VT, R, RC_COORD_EXACT>), dim3(blocks), dim3(FC_THREADS), 0, st,
