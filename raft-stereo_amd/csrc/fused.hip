@@ -264,33 +264,40 @@ __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __r
       // channel planes x the wave's 64 pixels.  Straight from the accumulators a store covers 64 bytes of 16
       // planes, which merges in L2 but rules out non-temporal stores for outputs beyond the Infinity Cache.
       constexpr int PITCH = 136;
-      __shared__ __attribute__((aligned(16))) unsigned char otile[FC_THREADS / 64][FC_OUT * PITCH];
+      // (32 channels at a time: half the tile, twice the workgroups per CU)
+      __shared__ __attribute__((aligned(16))) unsigned char otile[FC_THREADS / 64][(FC_OUT / 2) * PITCH];
       unsigned char* tile = otile[wave];
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          float v[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = relu ? fmaxf(acc[s][t][r], 0.f) : acc[s][t][r];
-          const int px = 16 * s + 4 * g;  // natural gather order: pass s, row 4 g + r is pixel 16 s + 4 g + r
-          *reinterpret_cast<uint2*>(tile + (16 * t + li) * PITCH + px * 2) =
-              make_uint2(pack2<VT>(v[0], v[1]), pack2<VT>(v[2], v[3]));
-        }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the tile is this wave's own: no barrier
-      __builtin_amdgcn_wave_barrier();
       typedef uint32_t u4 __attribute__((ext_vector_type(4)));
       const int seg = lane & 7;
       const bool inside = it.p0 + 8 * seg < (int)HW;  // HW is a multiple of 8 here: a piece is inside or outside
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int ch = 8 * i + (lane >> 3);
-        const u4 w = *reinterpret_cast<const u4*>(tile + ch * PITCH + seg * 16);
-        u4* dst = reinterpret_cast<u4*>(obase + ((uint32_t)ch * (uint32_t)HW + (uint32_t)(8 * seg)));
-        if (inside) {
-          if (nts) __builtin_nontemporal_store(w, dst);  // wave-uniform
-          else *dst = w;
+      for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const int t = 2 * hf + tt;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = relu ? fmaxf(acc[s][t][r], 0.f) : acc[s][t][r];
+            const int px = 16 * s + 4 * g;  // natural gather order: pass s, row 4 g + r is pixel 16 s + 4 g + r
+            *reinterpret_cast<uint2*>(tile + (16 * tt + li) * PITCH + px * 2) =
+                make_uint2(pack2<VT>(v[0], v[1]), pack2<VT>(v[2], v[3]));
+          }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the tile is this wave's own: no barrier
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int cl = 8 * i + (lane >> 3), ch = 32 * hf + cl;
+          const u4 w = *reinterpret_cast<const u4*>(tile + cl * PITCH + seg * 16);
+          u4* dst = reinterpret_cast<u4*>(obase + ((uint32_t)ch * (uint32_t)HW + (uint32_t)(8 * seg)));
+          if (inside) {
+            if (nts) __builtin_nontemporal_store(w, dst);  // wave-uniform
+            else *dst = w;
+          }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the second half overwrites the tile
+        __builtin_amdgcn_wave_barrier();
       }
       return;
     }
