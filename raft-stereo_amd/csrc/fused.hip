@@ -56,6 +56,29 @@ template <typename VT> __device__ __forceinline__ uint32_t pack2(float lo, float
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, v2));
 }
 
+// one level's taps, two per dword (the odd one out paired with zero)
+template <typename VT, int NT, bool PIN>
+__device__ __forceinline__ void pack_level(const float (&tap)[NT], uint32_t (&pk)[(NT + 1) / 2]) {
+#pragma unroll
+  for (int j = 0; j < (NT + 1) / 2; ++j) {
+    pk[j] = pack2<VT>(tap[2 * j], 2 * j + 1 < NT ? tap[2 * j + 1] : 0.f);
+    if (PIN) asm volatile("" : "+v"(pk[j]));
+  }
+}
+
+// max(v, floor) of two values, packed to the 16-bit type (floor = 0: ReLU; -inf: none).  f16 has a packed max, and
+// rounding is monotone, so the maximum can be taken after the conversion: one instruction per pair
+template <typename VT> __device__ __forceinline__ uint32_t act_pack2(float lo, float hi, float floor) {
+  if constexpr (sizeof(VT) == 2 && !__is_same(VT, rc_bf16)) {
+    typedef VT v2 __attribute__((ext_vector_type(2)));
+    const f2v f = {lo, hi};
+    const v2 fl = {(VT)floor, (VT)floor};
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_convertvector(f, v2), fl));
+  } else {
+    return pack2<VT>(__builtin_amdgcn_fmed3f(lo, floor, __builtin_inff()), __builtin_amdgcn_fmed3f(hi, floor, __builtin_inff()));
+  }
+}
+
 __device__ __forceinline__ void swap16(float& x, float& y) {
   const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
   x = __uint_as_float(r[0]);
@@ -115,7 +138,8 @@ __device__ __forceinline__ void transpose_rows(uint32_t (&r)[4]) {
   swap32u(r[1], r[3]);
 }
 
-template <typename VT, int R, int MODE>
+// TILE: 16-bit outputs made of whole 16-byte pieces (decided by the launcher) leave through the LDS tile
+template <typename VT, int R, int MODE, bool TILE>
 __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __restrict__ vol, rc_dev_layout lay,
                                                                    const float* __restrict__ coords,
                                                                    int coords_channels,
@@ -131,13 +155,17 @@ __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __r
   static_assert(NT <= FC_SLOTS, "a level's taps must fit its slots");
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int item = blockIdx.x * (FC_THREADS / 64) + wave;  // (image, 64-pixel chunk), wave-uniform
-  if (item >= n_items) return;
+  // (image, 64-pixel chunk), wave-uniform.  A block's chunks are 256 consecutive pixels of ONE image (the
+  // launcher counts chunks_per_image in whole blocks): chunks past the end of the image gather its last pixel,
+  // store nothing, and still reach the block's barriers
+  const int item = blockIdx.x * (FC_THREADS / 64) + wave;
+  if (!TILE && item >= n_items) return;
   const int64_t HW_ = (int64_t)lay.H * lay.W1;
   // the lane's pixel inside the chunk (see the header): rows of the later MFMA land 16 consecutive pixels per lane
   // (16-bit outputs in whole 16-byte pieces go through an LDS tile instead and gather in natural order)
-  const bool vec = (HW_ * (int64_t)sizeof(VT)) % 16 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;  // wave-uniform
-  const bool natural = IS16 && vec;
+  static_assert(!TILE || IS16, "the LDS tile path is for 16-bit outputs");
+  const bool vec = TILE || ((HW_ * (int64_t)sizeof(VT)) % 16 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0);  // wave-uniform
+  constexpr bool natural = TILE;
   const int poff = natural ? lane : 32 * (lane >> 5) + 8 * ((lane & 15) >> 2) + 4 * ((lane >> 4) & 1) + (lane & 3);
   const px_item it = locate_item(item, chunks_per_image, lay.H, lay.W1, poff);
   const int b = it.b, h = it.h, w1g = it.w1;  // lanes past the end of the image repeat its last pixel (never stored)
@@ -147,8 +175,21 @@ __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __r
   const int L = lay.L;
 
   // ---- phase 1: the plain lookup's gather, one pixel per lane: taps of every level in registers
+#ifdef RC_LAB_FUSED
+  const int ab = nts >> 4;
+  nts = (ab & 4) ? 0 : (nts & 1);
+  const float x_ = (coords + uniform(((int64_t)b * coords_channels) * HW))[min(it.p0 + poff, (int)HW - 1)];
+  const float x = (ab & 8) ? 10.f + 0.001f * x_ : x_;
+  const int b_ = b, h_ = h, w1g_ = w1g;
+#define b ((ab & 8) ? 0 : b_)
+#define h ((ab & 8) ? 0 : h_)
+#define w1g ((ab & 8) ? 0 : w1g_)
+#else
+  constexpr int ab = 0;
   const float x = (coords + uniform(((int64_t)b * coords_channels) * HW))[min(it.p0 + poff, (int)HW - 1)];
+#endif
   float tap[RC_MAX_LEVELS][NT];
+  uint32_t pk[RC_MAX_LEVELS][NDW];  // 16-bit pyramids: the taps rounded to the pyramid's type, two per dword
 #pragma unroll
   for (int i = 0; i < RC_MAX_LEVELS; ++i)
 #pragma unroll
@@ -161,9 +202,17 @@ __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __r
     p0.windows(lay, 0, lo, hi);
     interp_taps<R, MODE, NW>(lo, p0.s_lo, lay.width[0], p0.x_lo, p0.f_lo, tap[0]);
     interp_taps<R, MODE, NW>(hi, p0.s_hi, lay.width[1], p0.x_hi, p0.f_hi, tap[1]);
+    if constexpr (IS16) {  // packed (and pinned: 10 registers instead of 18) while the second run is decoded
+      pack_level<VT, NT, true>(tap[0], pk[0]);
+      pack_level<VT, NT, true>(tap[1], pk[1]);
+    }
     p2.windows(lay, 2, lo, hi);
     interp_taps<R, MODE, NW>(lo, p2.s_lo, lay.width[2], p2.x_lo, p2.f_lo, tap[2]);
     interp_taps<R, MODE, NW>(hi, p2.s_hi, lay.width[3], p2.x_hi, p2.f_hi, tap[3]);
+    if constexpr (IS16) {
+      pack_level<VT, NT, false>(tap[2], pk[2]);
+      pack_level<VT, NT, false>(tap[3], pk[3]);
+    }
   } else {
     if (L >= 2) {
       PF pf;
@@ -187,13 +236,105 @@ __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __r
       sf.window(lay, 2, v);
       interp_taps<R, MODE, NW>(v, sf.pos.wbase, lay.width[2], sf.xi, sf.frac, tap[2]);
     }
+    if constexpr (IS16) {
+#pragma unroll
+      for (int i = 0; i < RC_MAX_LEVELS; ++i) pack_level<VT, NT, false>(tap[i], pk[i]);
+    }
   }
 
-  // weights (B operand: column = out channel 16 t + li, K slots of level g) and bias (C column li)
+#ifdef RC_LAB_FUSED
+#undef b
+#undef h
+#undef w1g
+#endif
   const int li = lane & 15;
+  VT* obase = out + uniform(((int64_t)b * FC_OUT) * HW + it.p0);
+
+  // ---- 16-bit pyramids: lane rows <-> levels (the MFMA A operand), shared by both output paths
+  uint32_t aq[4][8];  // [pass s][dword of the level's 16 slots] of lane (g, li): level g of the pixel of lane (s, li)
+  if constexpr (IS16) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j < NDW) {
+        uint32_t r[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = pk[i][j];
+        transpose_rows(r);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) aq[s][j] = r[s];
+      } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) aq[s][j] = 0u;
+      }
+    }
+    if constexpr (TILE) {
+      // ---- the main path (16-bit outputs in whole 16-byte pieces): 16 output channels at a time -- 8 MFMAs,
+      // activation on the packed pairs -- into an LDS tile [32 channels][the BLOCK's 256 pixels] (pitch 528 B:
+      // the 16 lanes of a lane row write 16 different bank groups), from which every store instruction writes
+      // 512 contiguous bytes of 2 channel planes.  The size of these pieces is what outputs beyond the Infinity
+      // Cache pay for: their stores are non-temporal (they go straight to memory), and a stream of 128-byte
+      // pieces -- what one wave's 64 pixels make -- into 64 planes reaches 2.4 TB/s where 512-byte pieces
+      // reach 3.6 (tools/lab_store_patterns.hip).  Straight from the accumulators a store would cover 64 bytes of
+      // 16 planes.
+      constexpr int PITCH = FC_THREADS * 2 + 16;
+      __shared__ __attribute__((aligned(16))) unsigned char tile[(FC_OUT / 2) * PITCH];
+      typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+      const float act_floor = relu ? 0.f : -__builtin_inff();
+      uint4 wq[4][2];
+      float bq[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        wq[t][0] = reinterpret_cast<const uint4*>(wpack)[(t * 2 + 0) * 64 + lane];
+        wq[t][1] = reinterpret_cast<const uint4*>(wpack)[(t * 2 + 1) * 64 + lane];
+        bq[t] = bias[16 * t + li];
+      }
+      const int p0b = it.p0 - 64 * wave;  // the block's first pixel
+      VT* oblk = out + uniform(((int64_t)b * FC_OUT) * HW + p0b);
+      constexpr int WPB = FC_THREADS / 64, LPR = FC_THREADS / 8;  // waves per block; lanes per tile row (16 B each)
+      constexpr int CPW = (FC_OUT / 2) / WPB, PPI = 64 / LPR;     // channels per wave and half; planes per instruction
+      const int seg = lane & (LPR - 1);
+      const bool inside = p0b + 8 * seg < (int)HW;  // HW is a multiple of 8 here: a piece is inside or outside
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          const int t = 2 * hf + tt;
+          const uint4 w0 = wq[t][0], w1 = wq[t][1];
+          const float bvt = bq[t];
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            f4v a = {bvt, bvt, bvt, bvt};
+            if (!(ab & 2)) {
+            a = mfma16<VT>(make_uint4(aq[s][0], aq[s][1], aq[s][2], aq[s][3]), w0, a);
+            if (NT > 8) a = mfma16<VT>(make_uint4(aq[s][4], aq[s][5], aq[s][6], aq[s][7]), w1, a);
+            } else { a[0] += __uint_as_float(aq[s][0] ^ w0.x); a[1] += __uint_as_float(aq[s][1] ^ w0.y); a[2] += __uint_as_float(aq[s][2] ^ w1.x); a[3] += __uint_as_float(aq[s][4] ^ w1.y); }
+            const int px = 64 * wave + 16 * s + 4 * g;  // natural gather order: pass s, row 4 g + r is pixel 16 s + 4 g + r
+            *reinterpret_cast<uint2*>(tile + (16 * tt + li) * PITCH + px * 2) =
+                make_uint2(act_pack2<VT>(a[0], a[1], act_floor), act_pack2<VT>(a[2], a[3], act_floor));
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < CPW / PPI; ++i) {
+          const int cl = CPW * wave + PPI * i + lane / LPR, ch = 32 * hf + cl;
+          const u4 w = *reinterpret_cast<const u4*>(tile + cl * PITCH + seg * 16);
+          u4* dst = reinterpret_cast<u4*>(oblk + ((uint32_t)ch * (uint32_t)HW + (uint32_t)(8 * seg)));
+          if (inside && !(ab & 1)) {
+            if (nts) __builtin_nontemporal_store(w, dst);  // wave-uniform
+            else *dst = w;
+          }
+        }
+        if (hf == 0) __syncthreads();  // reads done before the second half overwrites the tile
+      }
+      return;
+    }
+  }
+
+  // ---- the general path (f32 pyramids, odd sizes): all 64 channels' sums in registers
+  // weights (B operand: column = out channel 16 t + li, K slots of level g) and bias (C column li)
   uint4 wa16[4][2];
   float wa32[4][NT];
-  float bv[4];
+  f4v acc[4][4];  // [pass][t]
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     if constexpr (IS16) {
@@ -203,32 +344,11 @@ __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __r
 #pragma unroll
       for (int e = 0; e < NT; ++e) wa32[t][e] = reinterpret_cast<const float*>(wpack)[(t * 16 + e) * 64 + lane];
     }
-    bv[t] = bias[16 * t + li];
+    const float bvt = bias[16 * t + li];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc[s][t] = (f4v){bvt, bvt, bvt, bvt};
   }
-
-  f4v acc[4][4];  // [pass][t]
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int s = 0; s < 4; ++s) acc[s][t] = (f4v){bv[t], bv[t], bv[t], bv[t]};
-
-  // ---- phase 2: lane rows <-> levels, then the 1x1 convolution on the matrix cores
   if constexpr (IS16) {
-    uint32_t aq[4][8];  // [pass s][dword of the level's 16 slots] of lane (g, li): level g of the pixel of lane (s, li)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if (j < NDW) {
-        uint32_t r[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) r[i] = pack2<VT>(tap[i][2 * j], 2 * j + 1 < NT ? tap[i][2 * j + 1] : 0.f);
-        transpose_rows(r);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) aq[s][j] = r[s];
-      } else {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) aq[s][j] = 0u;
-      }
-    }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const uint4 a0 = make_uint4(aq[s][0], aq[s][1], aq[s][2], aq[s][3]);
@@ -256,52 +376,6 @@ __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __r
 
   // ---- phase 3: activation and stores.  acc[s][t][r] = channel 16 t + li of pixel 32 (s / 2) + 8 g + 4 (s % 2) + r:
   // per (t, s / 2) the lane holds 8 consecutive pixels of one channel plane
-  VT* obase = out + uniform(((int64_t)b * FC_OUT) * HW + it.p0);
-  if constexpr (IS16) {
-    if (vec) {
-      // 16-bit outputs go through a wave-private LDS tile [channel][64 pixels] (pitch 136 B: the 16 lanes of a
-      // lane row write 16 different bank pairs) so that every store instruction writes WHOLE 128-byte lines: 8
-      // channel planes x the wave's 64 pixels.  Straight from the accumulators a store covers 64 bytes of 16
-      // planes, which merges in L2 but rules out non-temporal stores for outputs beyond the Infinity Cache.
-      constexpr int PITCH = 136;
-      // (32 channels at a time: half the tile, twice the workgroups per CU)
-      __shared__ __attribute__((aligned(16))) unsigned char otile[FC_THREADS / 64][(FC_OUT / 2) * PITCH];
-      unsigned char* tile = otile[wave];
-      typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-      const int seg = lane & 7;
-      const bool inside = it.p0 + 8 * seg < (int)HW;  // HW is a multiple of 8 here: a piece is inside or outside
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const int t = 2 * hf + tt;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = relu ? fmaxf(acc[s][t][r], 0.f) : acc[s][t][r];
-            const int px = 16 * s + 4 * g;  // natural gather order: pass s, row 4 g + r is pixel 16 s + 4 g + r
-            *reinterpret_cast<uint2*>(tile + (16 * tt + li) * PITCH + px * 2) =
-                make_uint2(pack2<VT>(v[0], v[1]), pack2<VT>(v[2], v[3]));
-          }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the tile is this wave's own: no barrier
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int cl = 8 * i + (lane >> 3), ch = 32 * hf + cl;
-          const u4 w = *reinterpret_cast<const u4*>(tile + cl * PITCH + seg * 16);
-          u4* dst = reinterpret_cast<u4*>(obase + ((uint32_t)ch * (uint32_t)HW + (uint32_t)(8 * seg)));
-          if (inside) {
-            if (nts) __builtin_nontemporal_store(w, dst);  // wave-uniform
-            else *dst = w;
-          }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the second half overwrites the tile
-        __builtin_amdgcn_wave_barrier();
-      }
-      return;
-    }
-  }
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const uint32_t plane = (uint32_t)(16 * t + li) * (uint32_t)HW;
@@ -347,21 +421,35 @@ __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __r
 template <typename VT, int R>
 int launch_fused(const void* vol, rc_dev_layout d, const float* coords, int cc, const void* wpack,
                  const float* bias, void* out, int mode, int relu, hipStream_t st) {
-  const int chunks = (d.H * d.W1 + 63) / 64;
+  constexpr int WPB = FC_THREADS / 64;
+  const int chunks = (d.H * d.W1 + FC_THREADS - 1) / FC_THREADS * WPB;  // whole blocks per image
   const int n_items = (int)((int64_t)d.B * chunks);
   const int blocks = (n_items + (FC_THREADS / 64) - 1) / (FC_THREADS / 64);
   // outputs that cannot stay in the Infinity Cache until their consumer runs leave through non-temporal stores
   // (the same rule and threshold as the plain lookup, lookup.hip); 16-bit outputs only: their stores cover whole lines
-  const int nts = sizeof(VT) == 2 && (int64_t)d.B * FC_OUT * d.H * d.W1 * (int64_t)sizeof(VT) > (160ll << 20);
-  if (mode == RC_COORD_EXACT) {
-    set_row_bias(d, vt_info<VT>::RB, pair_info<vt_info<VT>::RB, R, RC_COORD_EXACT>::NW2);
-    hipLaunchKernelGGL((lookup_convc1_kernel<VT, R, RC_COORD_EXACT>), dim3(blocks), dim3(FC_THREADS), 0, st,
-                       (const VT*)vol, d, coords, cc, (const VT*)wpack, bias, (VT*)out, chunks, n_items, relu, nts);
-  } else {
-    set_row_bias(d, vt_info<VT>::RB, pair_info<vt_info<VT>::RB, R, RC_COORD_GRIDSAMPLE>::NW2);
-    hipLaunchKernelGGL((lookup_convc1_kernel<VT, R, RC_COORD_GRIDSAMPLE>), dim3(blocks), dim3(FC_THREADS), 0, st,
-                       (const VT*)vol, d, coords, cc, (const VT*)wpack, bias, (VT*)out, chunks, n_items, relu, nts);
+  int nts = sizeof(VT) == 2 && (int64_t)d.B * FC_OUT * d.H * d.W1 * (int64_t)sizeof(VT) > (160ll << 20);
+#ifdef RC_LAB_FUSED
+  if (const char* e = getenv("RC_LAB_FUSED")) nts |= atoi(e) << 4;
+#endif
+  constexpr bool IS16 = sizeof(VT) == 2;
+  const bool tile = IS16 && ((int64_t)d.H * d.W1) % 8 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+#define RC_LAUNCH(MODE, TILE)                                                                                  \
+  do {                                                                                                         \
+    set_row_bias(d, vt_info<VT>::RB, pair_info<vt_info<VT>::RB, R, MODE>::NW2);                               \
+    hipLaunchKernelGGL((lookup_convc1_kernel<VT, R, MODE, TILE>), dim3(blocks), dim3(FC_THREADS), 0, st,       \
+                       (const VT*)vol, d, coords, cc, (const VT*)wpack, bias, (VT*)out, chunks, n_items, relu, \
+                       nts);                                                                                   \
+  } while (0)
+  if constexpr (IS16) {
+    if (tile) {
+      if (mode == RC_COORD_EXACT) RC_LAUNCH(RC_COORD_EXACT, true);
+      else RC_LAUNCH(RC_COORD_GRIDSAMPLE, true);
+      return rc_check_launch("rc_lookup_convc1_fwd");
+    }
   }
+  if (mode == RC_COORD_EXACT) RC_LAUNCH(RC_COORD_EXACT, false);
+  else RC_LAUNCH(RC_COORD_GRIDSAMPLE, false);
+#undef RC_LAUNCH
   return rc_check_launch("rc_lookup_convc1_fwd");
 }
 
