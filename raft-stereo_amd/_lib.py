@@ -19,7 +19,8 @@ RC_WRAP_ROWS = 32
 RC_VERSION = 200
 
 LIB_NAME = "libraftcorr_hip.so"
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+# RAFTCORR_LIB: another build of the same library (kernel A/B labs under tools/); it must exist and export everything
+LIB_PATH = os.environ.get("RAFTCORR_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 
 class Layout(C.Structure):

@@ -42,12 +42,15 @@ constexpr int FC_OUT = RC_CONVC1_OUT;  // output channels of convc1 (core/update
 constexpr int FC_SLOTS = 16;           // tap slots per level in the packed weights
 constexpr int FC_THREADS = 256;
 
-template <typename T> __device__ __forceinline__ f4v mfma16(uint4 a, uint4 b, f4v c);
-template <> __device__ __forceinline__ f4v mfma16<rc_half>(uint4 a, uint4 b, f4v c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8v, a), __builtin_bit_cast(h8v, b), c, 0, 0, 0);
+typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+typedef short s4v __attribute__((ext_vector_type(4)));
+// 16 pixels x 16 output channels += [16 x 16 tap slots] . [16 slots x 16]: a lane gives 4 slots of each operand
+template <typename T> __device__ __forceinline__ f4v mfma16(uint2 a, uint2 b, f4v c);
+template <> __device__ __forceinline__ f4v mfma16<rc_half>(uint2 a, uint2 b, f4v c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h4v, a), __builtin_bit_cast(h4v, b), c, 0, 0, 0);
 }
-template <> __device__ __forceinline__ f4v mfma16<rc_bf16>(uint4 a, uint4 b, f4v c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8v, a), __builtin_bit_cast(b8v, b), c, 0, 0, 0);
+template <> __device__ __forceinline__ f4v mfma16<rc_bf16>(uint2 a, uint2 b, f4v c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s4v, a), __builtin_bit_cast(s4v, b), c, 0, 0, 0);
 }
 
 template <typename VT> __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
@@ -94,9 +97,9 @@ template <typename A> __device__ __forceinline__ A pick4(const A (&a)[RC_MAX_LEV
   return i == 0 ? a[0] : (i == 1 ? a[1] : (i == 2 ? a[2] : a[3]));
 }
 
-// Packed weights (FC_OUT * 64 elements of the pyramid's type), t = out / 16, lane = 16 g + li,
-// out = 16 t + li, tap slot of level g:
-//   16-bit: [(t*2 + half)*64 + lane]*8 + e   <- W[out][g*NT + 8*half + e]
+// Packed weights (at most FC_OUT * 64 elements of the pyramid's type), t = out / 16, lane = 16 g + li,
+// out = 16 t + li, tap slot of level g; NM = ceil(NT / 4) MFMA steps of 16 slots (4 per level):
+//   16-bit: [((t*NM + m)*64 + lane)*4 + e]   <- W[out][g*NT + 4*m + e]
 //   f32:    [(t*16 + e)*64 + lane]           <- W[out][g*NT + e]
 // zero where the level or the tap does not exist.
 template <typename T>
@@ -106,10 +109,11 @@ __global__ __launch_bounds__(256) void convc1_pack_kernel(const float* __restric
   if (idx >= FC_OUT * 64) return;
   int t, lane, tap;
   if (sizeof(T) == 2) {
-    const int e = idx & 7, half = (idx >> 9) & 1;
-    lane = (idx >> 3) & 63;
-    t = idx >> 10;
-    tap = 8 * half + e;
+    const int NM = (NT + 3) / 4, e = idx & 3, tm = idx >> 8;
+    lane = (idx >> 2) & 63;
+    t = tm / NM;
+    tap = 4 * (tm - t * NM) + e;
+    if (t >= 4) return;  // beyond the 4 NM fragments in use
   } else {
     lane = idx & 63;
     tap = (idx >> 6) & 15;
@@ -152,6 +156,7 @@ __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __r
   using SF = single_fetch<VT, R, MODE>;
   constexpr int NT = 2 * R + 1, NW = PF::PI::NW;
   constexpr int NDW = (NT + 1) / 2;  // packed dwords per level (16-bit)
+  constexpr int NM = (NT + 3) / 4;   // MFMA steps (16-bit): 16 tap slots each, 4 per level
   static_assert(NT <= FC_SLOTS, "a level's taps must fit its slots");
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -175,19 +180,7 @@ __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __r
   const int L = lay.L;
 
   // ---- phase 1: the plain lookup's gather, one pixel per lane: taps of every level in registers
-#ifdef RC_LAB_FUSED
-  const int ab = nts >> 4;
-  nts = (ab & 4) ? 0 : (nts & 1);
-  const float x_ = (coords + uniform(((int64_t)b * coords_channels) * HW))[min(it.p0 + poff, (int)HW - 1)];
-  const float x = (ab & 8) ? 10.f + 0.001f * x_ : x_;
-  const int b_ = b, h_ = h, w1g_ = w1g;
-#define b ((ab & 8) ? 0 : b_)
-#define h ((ab & 8) ? 0 : h_)
-#define w1g ((ab & 8) ? 0 : w1g_)
-#else
-  constexpr int ab = 0;
   const float x = (coords + uniform(((int64_t)b * coords_channels) * HW))[min(it.p0 + poff, (int)HW - 1)];
-#endif
   float tap[RC_MAX_LEVELS][NT];
   uint32_t pk[RC_MAX_LEVELS][NDW];  // 16-bit pyramids: the taps rounded to the pyramid's type, two per dword
 #pragma unroll
@@ -242,19 +235,14 @@ __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __r
     }
   }
 
-#ifdef RC_LAB_FUSED
-#undef b
-#undef h
-#undef w1g
-#endif
   const int li = lane & 15;
   VT* obase = out + uniform(((int64_t)b * FC_OUT) * HW + it.p0);
 
   // ---- 16-bit pyramids: lane rows <-> levels (the MFMA A operand), shared by both output paths
-  uint32_t aq[4][8];  // [pass s][dword of the level's 16 slots] of lane (g, li): level g of the pixel of lane (s, li)
+  uint32_t aq[4][2 * NM];  // [pass s][dword of the level's 4 NM slots] of lane (g, li): level g of the pixel of lane (s, li)
   if constexpr (IS16) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < 2 * NM; ++j) {
       if (j < NDW) {
         uint32_t r[4];
 #pragma unroll
@@ -280,12 +268,12 @@ __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __r
       __shared__ __attribute__((aligned(16))) unsigned char tile[(FC_OUT / 2) * PITCH];
       typedef uint32_t u4 __attribute__((ext_vector_type(4)));
       const float act_floor = relu ? 0.f : -__builtin_inff();
-      uint4 wq[4][2];
+      uint2 wq[4][NM];
       float bq[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        wq[t][0] = reinterpret_cast<const uint4*>(wpack)[(t * 2 + 0) * 64 + lane];
-        wq[t][1] = reinterpret_cast<const uint4*>(wpack)[(t * 2 + 1) * 64 + lane];
+#pragma unroll
+        for (int m = 0; m < NM; ++m) wq[t][m] = reinterpret_cast<const uint2*>(wpack)[(t * NM + m) * 64 + lane];
         bq[t] = bias[16 * t + li];
       }
       const int p0b = it.p0 - 64 * wave;  // the block's first pixel
@@ -299,15 +287,12 @@ __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __r
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
           const int t = 2 * hf + tt;
-          const uint4 w0 = wq[t][0], w1 = wq[t][1];
           const float bvt = bq[t];
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             f4v a = {bvt, bvt, bvt, bvt};
-            if (!(ab & 2)) {
-            a = mfma16<VT>(make_uint4(aq[s][0], aq[s][1], aq[s][2], aq[s][3]), w0, a);
-            if (NT > 8) a = mfma16<VT>(make_uint4(aq[s][4], aq[s][5], aq[s][6], aq[s][7]), w1, a);
-            } else { a[0] += __uint_as_float(aq[s][0] ^ w0.x); a[1] += __uint_as_float(aq[s][1] ^ w0.y); a[2] += __uint_as_float(aq[s][2] ^ w1.x); a[3] += __uint_as_float(aq[s][4] ^ w1.y); }
+#pragma unroll
+            for (int m = 0; m < NM; ++m) a = mfma16<VT>(make_uint2(aq[s][2 * m], aq[s][2 * m + 1]), wq[t][m], a);
             const int px = 64 * wave + 16 * s + 4 * g;  // natural gather order: pass s, row 4 g + r is pixel 16 s + 4 g + r
             *reinterpret_cast<uint2*>(tile + (16 * tt + li) * PITCH + px * 2) =
                 make_uint2(act_pack2<VT>(a[0], a[1], act_floor), act_pack2<VT>(a[2], a[3], act_floor));
@@ -319,9 +304,15 @@ __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __r
           const int cl = CPW * wave + PPI * i + lane / LPR, ch = 32 * hf + cl;
           const u4 w = *reinterpret_cast<const u4*>(tile + cl * PITCH + seg * 16);
           u4* dst = reinterpret_cast<u4*>(oblk + ((uint32_t)ch * (uint32_t)HW + (uint32_t)(8 * seg)));
-          if (inside && !(ab & 1)) {
-            if (nts) __builtin_nontemporal_store(w, dst);  // wave-uniform
+          if (inside) {
+#ifdef RC_LAB_STORE_POLICY
+            asm volatile("global_store_dwordx4 %0, %1, off " RC_LAB_STORE_POLICY ::"v"(dst), "v"(w) : "memory");
+#else
+            // (wave-uniform.  Spelled out: of `if (nts) __builtin_nontemporal_store(..) else plain store` the
+            // compiler makes ONE plain store -- it merges the two arms and the hint is lost)
+            if (nts) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(w) : "memory");
             else *dst = w;
+#endif
           }
         }
         if (hf == 0) __syncthreads();  // reads done before the second half overwrites the tile
@@ -332,14 +323,14 @@ __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __r
 
   // ---- the general path (f32 pyramids, odd sizes): all 64 channels' sums in registers
   // weights (B operand: column = out channel 16 t + li, K slots of level g) and bias (C column li)
-  uint4 wa16[4][2];
+  uint2 wa16[4][NM];
   float wa32[4][NT];
   f4v acc[4][4];  // [pass][t]
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     if constexpr (IS16) {
-      wa16[t][0] = reinterpret_cast<const uint4*>(wpack)[(t * 2 + 0) * 64 + lane];
-      wa16[t][1] = reinterpret_cast<const uint4*>(wpack)[(t * 2 + 1) * 64 + lane];
+#pragma unroll
+      for (int m = 0; m < NM; ++m) wa16[t][m] = reinterpret_cast<const uint2*>(wpack)[(t * NM + m) * 64 + lane];
     } else {
 #pragma unroll
       for (int e = 0; e < NT; ++e) wa32[t][e] = reinterpret_cast<const float*>(wpack)[(t * 16 + e) * 64 + lane];
@@ -351,13 +342,11 @@ __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __r
   if constexpr (IS16) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const uint4 a0 = make_uint4(aq[s][0], aq[s][1], aq[s][2], aq[s][3]);
-      const uint4 a1 = make_uint4(aq[s][4], aq[s][5], aq[s][6], aq[s][7]);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        acc[s][t] = mfma16<VT>(a0, wa16[t][0], acc[s][t]);
-        if (NT > 8) acc[s][t] = mfma16<VT>(a1, wa16[t][1], acc[s][t]);
-      }
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int m = 0; m < NM; ++m)
+          acc[s][t] = mfma16<VT>(make_uint2(aq[s][2 * m], aq[s][2 * m + 1]), wa16[t][m], acc[s][t]);
     }
   } else {
 #pragma unroll
@@ -396,17 +385,11 @@ __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __r
           if constexpr (IS16) {
             typedef uint32_t u4 __attribute__((ext_vector_type(4)));
             const u4 w = {pack2<VT>(v[0], v[1]), pack2<VT>(v[2], v[3]), pack2<VT>(v[4], v[5]), pack2<VT>(v[6], v[7])};
-            if (nts) __builtin_nontemporal_store(w, reinterpret_cast<u4*>(dst));  // wave-uniform
-            else *reinterpret_cast<u4*>(dst) = w;
+            *reinterpret_cast<u4*>(dst) = w;
           } else {
             const f4v w0 = {v[0], v[1], v[2], v[3]}, w1 = {v[4], v[5], v[6], v[7]};
-            if (nts) {
-              __builtin_nontemporal_store(w0, reinterpret_cast<f4v*>(dst));
-              __builtin_nontemporal_store(w1, reinterpret_cast<f4v*>(dst + 4));
-            } else {
-              *reinterpret_cast<f4v*>(dst) = w0;
-              *reinterpret_cast<f4v*>(dst + 4) = w1;
-            }
+            *reinterpret_cast<f4v*>(dst) = w0;
+            *reinterpret_cast<f4v*>(dst + 4) = w1;
           }
         }
       } else {
@@ -426,11 +409,9 @@ int launch_fused(const void* vol, rc_dev_layout d, const float* coords, int cc, 
   const int n_items = (int)((int64_t)d.B * chunks);
   const int blocks = (n_items + (FC_THREADS / 64) - 1) / (FC_THREADS / 64);
   // outputs that cannot stay in the Infinity Cache until their consumer runs leave through non-temporal stores
-  // (the same rule and threshold as the plain lookup, lookup.hip); 16-bit outputs only: their stores cover whole lines
-  int nts = sizeof(VT) == 2 && (int64_t)d.B * FC_OUT * d.H * d.W1 * (int64_t)sizeof(VT) > (160ll << 20);
-#ifdef RC_LAB_FUSED
-  if (const char* e = getenv("RC_LAB_FUSED")) nts |= atoi(e) << 4;
-#endif
+  // (the same rule and threshold as the plain lookup, lookup.hip); the LDS-tile path only: its stores cover
+  // 512 contiguous bytes
+  const int nts = sizeof(VT) == 2 && (int64_t)d.B * FC_OUT * d.H * d.W1 * (int64_t)sizeof(VT) > (160ll << 20);
   constexpr bool IS16 = sizeof(VT) == 2;
   const bool tile = IS16 && ((int64_t)d.H * d.W1) % 8 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
 #define RC_LAUNCH(MODE, TILE)                                                                                  \

@@ -35,8 +35,12 @@ __device__ __forceinline__ void store_taps(float* __restrict__ out, int64_t plan
 #pragma unroll
   for (int k = 0; k < NT; ++k) {
     float* dst = (out + uniform(plane0 + k * HW)) + lane;
+#ifdef RC_LAB_STORE_POLICY
+    asm volatile("global_store_dword %0, %1, off " RC_LAB_STORE_POLICY ::"v"(dst), "v"(tap[k]) : "memory");
+#else
     if constexpr (NTS) __builtin_nontemporal_store(tap[k], dst);
     else *dst = tap[k];
+#endif
   }
 }
 
