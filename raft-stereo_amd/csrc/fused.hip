@@ -298,22 +298,44 @@ __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __r
                 make_uint2(act_pack2<VT>(a[0], a[1], act_floor), act_pack2<VT>(a[2], a[3], act_floor));
           }
         }
+        if (hf == 0) {
+          // the stores below are written in assembly and the compiler does not count them: a wait for the second
+          // half's weights after them would wait for them too.  Naming the registers puts it here.
+#pragma unroll
+          for (int t = 2; t < 4; ++t) {
+#pragma unroll
+            for (int m = 0; m < NM; ++m) asm volatile("" : "+v"(wq[t][m].x), "+v"(wq[t][m].y));
+            asm volatile("" : "+v"(bq[t]));
+          }
+        }
         __syncthreads();
+        u4 w[CPW / PPI];
+        u4* dst[CPW / PPI];
 #pragma unroll
         for (int i = 0; i < CPW / PPI; ++i) {
           const int cl = CPW * wave + PPI * i + lane / LPR, ch = 32 * hf + cl;
-          const u4 w = *reinterpret_cast<const u4*>(tile + cl * PITCH + seg * 16);
-          u4* dst = reinterpret_cast<u4*>(oblk + ((uint32_t)ch * (uint32_t)HW + (uint32_t)(8 * seg)));
-          if (inside) {
+          w[i] = *reinterpret_cast<const u4*>(tile + cl * PITCH + seg * 16);
+          dst[i] = reinterpret_cast<u4*>(oblk + ((uint32_t)ch * (uint32_t)HW + (uint32_t)(8 * seg)));
+        }
+        if (inside) {
+          // Spelled out: of `if (nts) __builtin_nontemporal_store(..) else plain store` the compiler makes ONE
+          // plain store (it merges the two arms and the hint is lost); otherwise agent-scope stores, as in the
+          // plain lookup (store_taps, lookup.hip)
 #ifdef RC_LAB_STORE_POLICY
-            asm volatile("global_store_dwordx4 %0, %1, off " RC_LAB_STORE_POLICY ::"v"(dst), "v"(w) : "memory");
+#pragma unroll
+          for (int i = 0; i < CPW / PPI; ++i)
+            asm volatile("global_store_dwordx4 %0, %1, off " RC_LAB_STORE_POLICY ::"v"(dst[i]), "v"(w[i]) : "memory");
 #else
-            // (wave-uniform.  Spelled out: of `if (nts) __builtin_nontemporal_store(..) else plain store` the
-            // compiler makes ONE plain store -- it merges the two arms and the hint is lost)
-            if (nts) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(w) : "memory");
-            else *dst = w;
-#endif
+          if (nts) {  // wave-uniform
+#pragma unroll
+            for (int i = 0; i < CPW / PPI; ++i)
+              asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst[i]), "v"(w[i]) : "memory");
+          } else {
+#pragma unroll
+            for (int i = 0; i < CPW / PPI; ++i)
+              asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst[i]), "v"(w[i]) : "memory");
           }
+#endif
         }
         if (hf == 0) __syncthreads();  // reads done before the second half overwrites the tile
       }

@@ -27,19 +27,24 @@ struct lk_update {
   float* flow_out;     // [B,2,H,W1]
 };
 
-// Stores the 2r+1 taps of one level: one aligned 256-byte piece per channel plane and wave.  NTS: non-temporal
-// stores, for outputs far larger than the caches (they are read once, by the next kernel).
+// Stores the 2r+1 taps of one level: one aligned 256-byte piece per channel plane and wave.
+//   NTS:  non-temporal stores, for outputs far larger than the caches (they are read once, by the next kernel);
+//   else: agent-scope stores (`sc1`): written through the XCD's L2 as the kernel runs.  Plain stores stay in
+//         that L2 as dirty lines and are written back when the kernel ends -- a tail with nothing to overlap
+//         (KITTI, 8 pairs: 11.1 us against 9.0); the kernel that reads the taps next finds them in the
+//         Infinity Cache either way (tools/lab_consumer.py: lookup + cast 20.0 us with both).
 template <int NT, bool NTS>
 __device__ __forceinline__ void store_taps(float* __restrict__ out, int64_t plane0, int64_t HW, int lane,
                                            const float (&tap)[NT]) {
 #pragma unroll
   for (int k = 0; k < NT; ++k) {
-    float* dst = (out + uniform(plane0 + k * HW)) + lane;
+    float* base = out + uniform(plane0 + k * HW);  // scalar
 #ifdef RC_LAB_STORE_POLICY
-    asm volatile("global_store_dword %0, %1, off " RC_LAB_STORE_POLICY ::"v"(dst), "v"(tap[k]) : "memory");
+    asm volatile("global_store_dword %0, %1, %2 " RC_LAB_STORE_POLICY ::"v"(lane * 4), "v"(tap[k]), "s"(base) : "memory");
 #else
-    if constexpr (NTS) __builtin_nontemporal_store(tap[k], dst);
-    else *dst = tap[k];
+    // (spelled out so that the plane's base stays in scalar registers: the builtin takes a 64-bit vector address)
+    if constexpr (NTS) asm volatile("global_store_dword %0, %1, %2 nt" ::"v"(lane * 4), "v"(tap[k]), "s"(base) : "memory");
+    else asm volatile("global_store_dword %0, %1, %2 sc1" ::"v"(lane * 4), "v"(tap[k]), "s"(base) : "memory");
 #endif
   }
 }
@@ -83,9 +88,17 @@ __global__ __launch_bounds__(LK_THREADS) void lookup_fwd_kernel(const VT* __rest
   }
   const int64_t out_u = ((int64_t)b * L * NT) * HW + it.p0;  // wave-uniform
 
-  auto finish_pair = [&](PF& pf, int i) {
+  // `pending`: a run whose loads are still in flight.  The stores below are written in assembly, so the
+  // compiler does not count them: its wait for `pending` after them would be a wait for them too (a store's
+  // acknowledgement takes far longer than a load that was issued long before).  Naming the registers here
+  // puts that wait before the first store.
+  auto finish_pair = [&](PF& pf, int i, PF* pending) {
     float lo[NW], hi[NW], tap[NT];
     pf.windows(lay, i, lo, hi);
+    if (pending) {
+#pragma unroll
+      for (int k = 0; k < PF::PI::ND; ++k) asm volatile("" : "+v"(pending->d[k]));
+    }
     interp_taps<R, MODE, NW>(lo, pf.s_lo, lay.width[i], pf.x_lo, pf.f_lo, tap);
     store_taps<NT, NTS>(out, out_u + (int64_t)i * NT * HW, HW, lane, tap);
     interp_taps<R, MODE, NW>(hi, pf.s_hi, lay.width[i + 1], pf.x_hi, pf.f_hi, tap);
@@ -96,15 +109,15 @@ __global__ __launch_bounds__(LK_THREADS) void lookup_fwd_kernel(const VT* __rest
     PF p0, p2;
     p0.issue(vol, lay, 0, x, w1, h, b, blk_bytes);
     p2.issue(vol, lay, 2, x, w1, h, b, blk_bytes);
-    finish_pair(p0, 0);
-    finish_pair(p2, 2);
+    finish_pair(p0, 0, &p2);
+    finish_pair(p2, 2, nullptr);
   } else {
 #pragma unroll
     for (int i = 0; i + 1 < RC_MAX_LEVELS; i += 2) {
       if (i + 1 < L) {  // wave-uniform
         PF pf;
         pf.issue(vol, lay, i, x, w1, h, b, blk_bytes);
-        finish_pair(pf, i);
+        finish_pair(pf, i, nullptr);
       }
     }
     if (L & 1) {  // the last level stands alone
@@ -513,9 +526,9 @@ int dispatch_adjoint_dense(const adj_lists& lists, const adj_dims& d, void* dC, 
 }
 
 // Outputs beyond this size cannot stay in the 256 MiB Infinity Cache until their consumer reads them: they
-// are written with non-temporal stores (KITTI, 64 pairs: 104 -> 94 us).  Smaller outputs keep plain stores:
-// non-temporal ones make this kernel faster there too (8 pairs: 12.2 -> 10.5 us) but the consumer then
-// reads from HBM and loses twice that (lookup + cast + convc1: 102.9 -> 106.3 us), measured in bench.py.
+// are written with non-temporal stores (KITTI, 64 pairs: 104 -> 94 us).  Non-temporal stores make the kernel
+// faster on smaller outputs too (8 pairs: 11.1 -> 9.7 us) but the consumer then pays more than that
+// (lookup + cast: 20.0 -> 20.9 us): those use agent-scope stores instead (store_taps).
 constexpr int64_t LK_NT_STORE_BYTES = 160ll << 20;
 
 template <typename VT, int R, int MODE>
