@@ -597,6 +597,32 @@ def test_lookup_convc1_equals_unfused_at_full_size(R, dtype, shape, mode):
     assert rel(act, ref.cpu().numpy()) < tol
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("levels,radius", [(4, 1), (4, 2), (3, 3), (4, 5), (2, 6), (4, 7), (1, 4)])
+def test_lookup_convc1_tile_path_radii_levels_partial_blocks(R, dtype, levels, radius):
+    """The LDS-tile path of the fused kernel (16-bit outputs made of whole 16-byte pieces) at every count of MFMA
+    steps (ceil((2r+1)/4) = 1..4) and level count, on images of 5.47 workgroups (H*W = 1400 = 8 * 175: the last
+    workgroup of every image is part empty, one of its waves wholly), three images, with and without the ReLU:
+    fused == conv2d(lookup) computed with torch on the library's own lookup."""
+    gen = torch.Generator(device="cuda").manual_seed(100 + 10 * levels + radius)
+    B, D, H, W = 3, 64, 7, 200
+    f1 = torch.randn((B, D, H, W), generator=gen, device="cuda").to(dtype)
+    f2 = torch.randn((B, D, H, W), generator=gen, device="cuda").to(dtype)
+    c = torch.from_numpy(O.synthetic_coords(B, H, W, seed=7)).cuda()
+    K = levels * (2 * radius + 1)
+    wgt = torch.randn((64, K, 1, 1), generator=gen, device="cuda") * 0.3
+    bias = torch.randn((64,), generator=gen, device="cuda")
+    with torch.no_grad():
+        blk = R.CorrBlock1DHip(f1, f2, num_levels=levels, radius=radius)
+        lin = torch.nn.functional.conv2d(blk(c).to(dtype).float(), wgt.to(dtype).float(), bias)
+        for relu in (True, False):
+            act = blk.lookup_convc1(c, wgt, bias, relu=relu)
+            assert act.dtype == dtype and tuple(act.shape) == (B, 64, H, W)
+            ref = torch.relu(lin) if relu else lin
+            assert rel(act, ref.cpu().numpy()) < TOL16[dtype]
+        assert (blk.lookup_convc1(c, wgt, bias, relu=False) < 0).any()
+
+
 def test_lookup_convc1_rejects_bad_weights(R):
     f = torch.randn(1, 32, 2, 32, device="cuda")
     blk = R.CorrBlock1DHip(f, f)
