@@ -88,36 +88,40 @@ __global__ __launch_bounds__(LK_THREADS) void lookup_fwd_kernel(const VT* __rest
   }
   const int64_t out_u = ((int64_t)b * L * NT) * HW + it.p0;  // wave-uniform
 
-  // `pending`: a run whose loads are still in flight.  The stores below are written in assembly, so the
-  // compiler does not count them: its wait for `pending` after them would be a wait for them too (a store's
-  // acknowledgement takes far longer than a load that was issued long before).  Naming the registers here
-  // puts that wait before the first store.
-  auto finish_pair = [&](PF& pf, int i, PF* pending) {
-    float lo[NW], hi[NW], tap[NT];
-    pf.windows(lay, i, lo, hi);
-    if (pending) {
-#pragma unroll
-      for (int k = 0; k < PF::PI::ND; ++k) asm volatile("" : "+v"(pending->d[k]));
-    }
+  auto emit_pair = [&](PF& pf, int i, const float (&lo)[NW], const float (&hi)[NW]) {
+    float tap[NT];
     interp_taps<R, MODE, NW>(lo, pf.s_lo, lay.width[i], pf.x_lo, pf.f_lo, tap);
     store_taps<NT, NTS>(out, out_u + (int64_t)i * NT * HW, HW, lane, tap);
     interp_taps<R, MODE, NW>(hi, pf.s_hi, lay.width[i + 1], pf.x_hi, pf.f_hi, tap);
     store_taps<NT, NTS>(out, out_u + (int64_t)(i + 1) * NT * HW, HW, lane, tap);
+  };
+  auto finish_pair = [&](PF& pf, int i) {
+    float lo[NW], hi[NW];
+    pf.windows(lay, i, lo, hi);
+    emit_pair(pf, i, lo, hi);
   };
 
   if constexpr (ALL4) {
     PF p0, p2;
     p0.issue(vol, lay, 0, x, w1, h, b, blk_bytes);
     p2.issue(vol, lay, 2, x, w1, h, b, blk_bytes);
-    finish_pair(p0, 0, &p2);
-    finish_pair(p2, 2, nullptr);
+    float lo[NW], hi[NW];
+    p0.windows(lay, 0, lo, hi);
+    // The stores are written in assembly, so the compiler does not count them: its wait for the second run's
+    // loads after them would be a wait for them too (a store's acknowledgement takes far longer than a load
+    // that was issued long before).  Naming the registers here puts that wait before the first store.
+    // (Directly, not through a pointer or a reference parameter: that turns the array into scratch memory.)
+#pragma unroll
+    for (int k = 0; k < PF::PI::ND; ++k) asm volatile("" : "+v"(p2.d[k]));
+    emit_pair(p0, 0, lo, hi);
+    finish_pair(p2, 2);
   } else {
 #pragma unroll
     for (int i = 0; i + 1 < RC_MAX_LEVELS; i += 2) {
       if (i + 1 < L) {  // wave-uniform
         PF pf;
         pf.issue(vol, lay, i, x, w1, h, b, blk_bytes);
-        finish_pair(pf, i, nullptr);
+        finish_pair(pf, i);
       }
     }
     if (L & 1) {  // the last level stands alone

@@ -235,3 +235,36 @@ def test_bench_input_generator_matches_the_oracles():
         assert np.array_equal(bench.synthetic_coords(2, 9, 40, seed=5, adversarial=adv), ref(2, 9, 40, seed=5, adversarial=adv))
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert src.count("from oracle") == 1 and "oracle.reg_torch" in src       # the cpu_baseline leg only
+
+
+def test_no_kernel_went_to_scratch_memory():
+    """The build keeps the compiler's per-kernel resource report (raft-stereo_amd/csrc/*.usage.txt, Makefile).
+    Every kernel of the library is written to live in registers; a select between array elements or an array
+    reached through a pointer silently turns into scratch memory (twice in round 2: the f32 lookup ran at two
+    thirds of its speed, the bf16 lookup at half).  Allowed: the 16-bit build's variants for unaligned rows or
+    D != 256, which spill a few registers by design."""
+    import glob
+    import re
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "raft-stereo_amd", "csrc")
+    files = sorted(glob.glob(os.path.join(csrc, "*.usage.txt")))
+    sources = sorted(glob.glob(os.path.join(csrc, "*.hip")))
+    if not files:
+        pytest.skip("library was not built here by its Makefile (no resource reports)")
+    assert len(files) == len(sources), "a source file has no resource report: rebuild with make -C raft-stereo_amd/csrc"
+    allowed = re.compile(r"build16_kernelIDF16b?_?Li[01]E")      # FAST = 0 / 1
+    n_kernels, offenders = 0, []
+    for path in files:
+        name = None
+        for line in open(path):
+            m = re.search(r"remark: Function Name: (\S+)", line)
+            if m:
+                name = m.group(1)
+                n_kernels += 1
+                continue
+            m = re.search(r"remark:\s+ScratchSize \[bytes/lane\]: (\d+)", line)
+            if m and int(m.group(1)) > 0:
+                if allowed.search(name) and int(m.group(1)) <= 64:
+                    continue
+                offenders.append((os.path.basename(path), name, int(m.group(1))))
+    assert n_kernels > 300
+    assert not offenders, offenders
