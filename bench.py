@@ -650,17 +650,28 @@ def hbm_resident_lookup(cfg, device, seed, batch=64, passes=3):
                 algorithmic_bytes_per_launch=int(alg), traffic=measured_traffic("kitti", batch, "lookup_fwd_kernel"))
 
 
-def hip_graph_step(step, n=50):
-    """The same step (build/prepare + lookups) captured once in a HIP graph and replayed: what a
-    caller that captures its GRU loop pays per pair batch once launch overhead is gone.  Reported
-    beside `ms_per_step` (which stays the eager number); the library needs nothing special for this:
-    it neither allocates nor synchronises."""
-    with torch.no_grad():
+def hip_graph_step(cfg, device, seed, n=50):
+    """The same step (build/prepare + lookups, and for a training workload the backward to the feature maps)
+    captured once in a HIP graph and replayed: what a caller that captures its loop pays per pair batch once
+    launch and Python overhead are gone.  Reported beside `ms_per_step` (which stays the eager number); the
+    library needs nothing special for this: it neither allocates nor synchronises.  The step gets fresh input
+    tensors whose first passes run on the capture's side stream (torch wants the leaves' gradient accumulators
+    made there: with accumulators from earlier passes on the default stream the capture of the backward
+    crashed on the host).  Training: the replayed gradients are compared bit for bit with the eager ones."""
+    step = Step(cfg, device, seed)
+    ctx = torch.enable_grad() if cfg["train"] else torch.no_grad()
+    with ctx:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            step.run(record=False)
+            for _ in range(3):
+                step.run(record=False)
         torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        eager_grads = None
+        if cfg["train"]:
+            eager_grads = (step.f1.grad.clone(), step.f2.grad.clone())
+            step.f1.grad = step.f2.grad = None
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             step.run(record=False)
@@ -672,7 +683,11 @@ def hip_graph_step(step, n=50):
             graph.replay()
         b.record()
         b.synchronize()
-    return dict(hip_graph_ms_per_step=round(a.elapsed_time(b) / n, 4))
+    out = dict(hip_graph_ms_per_step=round(a.elapsed_time(b) / n, 4))
+    if eager_grads is not None:
+        out["hip_graph_grads_equal_eager"] = bool(torch.equal(step.f1.grad, eager_grads[0])
+                                                  and torch.equal(step.f2.grad, eager_grads[1]))
+    return out
 
 
 def cpu_baseline(cfg, budget_s=15.0):
@@ -826,7 +841,7 @@ def main():
         if args.debug_leg == "loop_eager":
             extra.update(refine_loop(step, cfg, device, capture=False, baseline=False))
         elif args.debug_leg == "graph_step":
-            extra.update(hip_graph_step(step))
+            extra.update(hip_graph_step(cfg, device, 1234 + rank))
         else:
             extra.update(refine_loop(step, cfg, device, capture=True, baseline=True))
         args.loop_only = True      # nothing else
@@ -845,8 +860,9 @@ def main():
         note("side legs done; training step")
         extra.update(refine_train_step(step, cfg, device, dist=dist))
         note("training step done")
-    if not cfg["train"] and world == 1 and not args.loop_only and not profiler:
-        extra.update(hip_graph_step(step))       # side metric; kept out of multi-rank runs (no capture beside RCCL)
+    if world == 1 and not args.loop_only and not profiler:
+        # side metric; kept out of multi-rank runs (no capture beside RCCL)
+        extra.update(hip_graph_step(cfg, device, 1234 + rank))
     if profiler:
         extra["profiler_attached"] = True
     if (args.workload == "kitti" and not args.batch and not args.dtype and rank == 0 and not args.loop_only

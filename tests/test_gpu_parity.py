@@ -772,6 +772,53 @@ def test_build_and_lookups_replay_from_a_hip_graph(R):
     assert all(torch.equal(a, b) for a, b in zip(captured, eager))
 
 
+def test_training_step_replays_from_a_hip_graph(R):
+    """Forward (build, lookups, fused convc1) AND backward to the feature maps and the layer's parameters
+    captured in one HIP graph: the replayed gradients equal the eager ones bit for bit.  The leaves are made
+    fresh and their first passes run on the capture's side stream (torch's rule for whole-network capture)."""
+    gen = torch.Generator(device="cuda").manual_seed(77)
+    B, D, H, W = 2, 64, 6, 96
+    coords = [torch.from_numpy(O.synthetic_coords(B, H, W, seed=s)).cuda() for s in (1, 2, 3)]
+    gout = torch.randn((B, 36, H, W), generator=gen, device="cuda")
+    gact = torch.randn((B, 64, H, W), generator=gen, device="cuda").bfloat16()
+    init = [torch.randn((B, D, H, W), generator=gen, device="cuda").bfloat16() for _ in range(2)]
+    init += [torch.randn((64, 36), generator=gen, device="cuda") * 0.2, torch.randn((64,), generator=gen, device="cuda")]
+
+    def leaves():
+        return [t.clone().requires_grad_(True) for t in init]
+
+    def step(f1, f2, w, b):
+        blk = R.CorrBlock1DHip(f1, f2)
+        outs = [blk(c) for c in coords[:2]] + [blk.lookup_convc1(coords[2], w, b)]
+        torch.autograd.backward(outs, [gout, gout, gact])
+
+    ref = leaves()
+    step(*ref)
+    torch.cuda.synchronize()
+    cap = leaves()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            for t in cap:
+                t.grad = None
+            step(*cap)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    for t in cap:
+        t.grad = None
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step(*cap)
+    for t in cap:
+        t.grad.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(cap, ref):
+        assert a.grad is not None and torch.equal(a.grad, b.grad)
+    assert float(cap[0].grad.float().abs().max()) > 0
+
+
 # ------------------------------------------------------------------ argument checking
 def test_argument_errors(R):
     f = torch.randn(1, 32, 2, 32, device="cuda")
