@@ -190,32 +190,54 @@ __global__ __launch_bounds__(256) void alt_fwd_kernel(const T* __restrict__ f1t,
     hi = min(hi, Wi - 1);
 
     const T* f2l = f2t + lay.f2_offset[i] + ((int64_t)bh * ((Wi + 15) >> 4)) * blk_elems + lane * EL;
-    for (int cb = lo >> 4; cb <= (hi >> 4); ++cb) {  // empty when lo > hi
-      // 16 right-image positions x 16 pixels on the matrix cores
-      const T* ap = f2l + cb * blk_elems;
-      uint4 av[NKC];
+    // the next block of positions is requested before the current one is multiplied (the trip count is 1-3 and
+    // not known to the compiler, which otherwise exposes one memory latency per block)
+    const int cb_end = __builtin_amdgcn_readfirstlane(hi >> 4);
+    int cb = __builtin_amdgcn_readfirstlane(lo >> 4);
+    uint4 av[NKC], nx[NKC];
+    auto fetch = [&](uint4 (&dstv)[NKC], int blk) {
+      const T* ap = f2l + blk * blk_elems;
 #pragma unroll
       for (int kc = 0; kc < NKC; ++kc)
-        if (FULL || kc < nkc) av[kc] = *reinterpret_cast<const uint4*>(ap + kc * 64 * EL);
+        if (FULL || kc < nkc) dstv[kc] = *reinterpret_cast<const uint4*>(ap + kc * 64 * EL);
+    };
+    // 16 right-image positions x 16 pixels on the matrix cores
+    auto multiply = [&](const uint4 (&a)[NKC], int blk) {
       f4v acc = (f4v)(0.f);
 #pragma unroll
       for (int kc = 0; kc < NKC; ++kc) {
         if (FULL || kc < nkc) {
           if constexpr (IS16) {
-            acc = mfma16<T>(__builtin_bit_cast(s8v, av[kc]), __builtin_bit_cast(s8v, bfrag[kc]), acc);
+            acc = mfma16<T>(__builtin_bit_cast(s8v, a[kc]), __builtin_bit_cast(s8v, bfrag[kc]), acc);
           } else {
-            const f4v a4 = __builtin_bit_cast(f4v, av[kc]), b4 = __builtin_bit_cast(f4v, bfrag[kc]);
+            const f4v a4 = __builtin_bit_cast(f4v, a[kc]), b4 = __builtin_bit_cast(f4v, bfrag[kc]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[e], b4[e], acc, 0, 0, 0);
           }
         }
       }
-      // lane holds C[w2 = cb*16 + 4g + r][this pixel]: keep what falls into the pixel's own window
+      // lane holds C[w2 = blk*16 + 4g + r][this pixel]: keep what falls into the pixel's own window
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int w2 = cb * 16 + 4 * g + r;
+        const int w2 = blk * 16 + 4 * g + r;
         const int j = w2 - base;
         if ((unsigned)j < (unsigned)NS && w2 < Wi) mywin[j] = acc[r];
+      }
+    };
+    if constexpr (!IS16) {  // f32 operands are twice the registers: one block at a time
+      for (; cb <= cb_end; ++cb) {
+        fetch(av, cb);
+        multiply(av, cb);
+      }
+    } else if (cb <= cb_end) {  // (nothing to do when lo > hi)
+      fetch(av, cb);
+      while (true) {  // two register sets take turns: no copies
+        if (cb < cb_end) fetch(nx, cb + 1);
+        multiply(av, cb);
+        if (++cb > cb_end) break;
+        if (cb < cb_end) fetch(av, cb + 1);
+        multiply(nx, cb);
+        if (++cb > cb_end) break;
       }
     }
     // the four lane groups of a pixel exchange through LDS: one wave, in-order LDS, no workgroup barrier
