@@ -125,6 +125,14 @@ __global__ __launch_bounds__(256) void to_fragments_kernel(const T* __restrict__
 }
 
 // FULL: Dp == DMAX, every operand load unconditional (the real model's D = 256).
+// A wave serves a PAIR of levels (i, i + 1), i even, of 16 pixels: pooling is linear, so the correlation with the
+// pooled right image is the mean of two correlations one level down,
+//     C_{i+1}[w1][j] = (C_i[w1][2j] + C_i[w1][2j+1]) / 2,
+// and because floor(x / 2^i) = 2 floor(x / 2^(i+1)) + bit, level i's window lies inside the run of 2 NS level-i
+// positions under level (i+1)'s window (the lookup of the materialised pyramid reads its levels the same way,
+// window.h).  The copies of f2 at the odd levels are never read: a third fewer operand bytes per lookup, and the
+// odd levels are means of fp32 sums instead of sums over features pooled and rounded to 16 bits -- closer to
+// the reference, which pools in fp32 (core/corr.py:104).
 template <typename T, int R, int MODE, bool FULL>
 __global__ __launch_bounds__(256) void alt_fwd_kernel(const T* __restrict__ f1t, const T* __restrict__ f2t,
                                                       alt_dev_layout lay, const float* __restrict__ coords,
@@ -134,24 +142,26 @@ __global__ __launch_bounds__(256) void alt_fwd_kernel(const T* __restrict__ f1t,
   constexpr int NT = 2 * R + 1;
   constexpr int EXT = MODE == RC_COORD_GRIDSAMPLE ? 1 : 0;  // grid_sample's fp32 round trip can move a tap by one
   constexpr int NS = NT + 1 + 2 * EXT;                      // correlation values a pixel's taps can touch
-  constexpr int PITCH = NS | 1;
+  constexpr int NR = 2 * NS;                                // ... of level i under the window of level i + 1
+  constexpr int PITCH = NR | 1;
   constexpr int EL = 16 / (int)sizeof(T);
   constexpr int KCH = 4 * EL;                               // K elements consumed per operand load
   constexpr int NKC = DMAX / KCH;
-  // a pixel's window of correlation values at the wave's level: slot j <-> w2 = base + j
-  __shared__ float win[RC_MAX_LEVELS][16][PITCH];
+  // a pixel's run of correlation values at the wave's even level: slot j <-> w2 = rs + j
+  __shared__ float win[4][16][PITCH];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, li = lane & 15;
-  // A workgroup owns 16 consecutive pixels of one image row, one wave per pyramid level (a level
-  // needs 1-3 operand blocks: short dependent chains, and the four waves share the pixels' operand
-  // through the L1).  Workgroup ids that agree mod 8 run on the same XCD: they get the same rows, so
-  // a row of fmap2 goes through one L2 only.
+  // A workgroup owns 32 consecutive pixels of one image row: wave = (block of 16 pixels, pair of levels).  A run
+  // needs 2-4 operand blocks, the two waves of a pixel block share its operand through the L1.  Workgroup ids
+  // that agree mod 8 run on the same XCD: they get the same rows, so a row of fmap2 goes through one L2 only.
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int bh = (slot / blocks_per_row) * 8 + xcd;
-  const int pb1 = slot % blocks_per_row;  // the workgroup's block of 16 pixels; wave = pyramid level
+  const int pb1 = (slot % blocks_per_row) * 2 + (wave >> 1);  // the wave's block of 16 pixels
+  const int i = 2 * (wave & 1);                               // its even level
   const int w1 = pb1 * 16 + li;
-  if (bh >= n_rows || pb1 * 16 >= lay.W1 || wave >= lay.L) return;  // wave-uniform
+  if (bh >= n_rows || pb1 * 16 >= lay.W1 || i >= lay.L) return;  // wave-uniform
+  const bool has_hi = i + 1 < lay.L;                             // wave-uniform
   const int b = bh / lay.H, h = bh - b * lay.H;
   const bool live = w1 < lay.W1;
   const int w1c = live ? w1 : lay.W1 - 1;
@@ -171,97 +181,117 @@ __global__ __launch_bounds__(256) void alt_fwd_kernel(const T* __restrict__ f1t,
   }
   const float x = coords[((int64_t)b * coords_channels) * HW + (int64_t)h * lay.W1 + w1c];
 
-  {
-    const int i = wave;
-    const int Wi = lay.width[i];
-    const float xi = x / (float)(1 << i);
-    const float xf = floorf(xi);
-    const int base = rc_safe_int(xf) - R - EXT;
-    float* mywin = &win[i][li][0];
+  const int Wlo = lay.width[i], Whi = has_hi ? lay.width[i + 1] : 0;
+  const float x_lo = x / (float)(1 << i), x_hi = x / (float)(2 << i);
+  const float f_lo = floorf(x_lo), f_hi = floorf(x_hi);
+  const int base_lo = rc_safe_int(f_lo) - R - EXT, base_hi = rc_safe_int(f_hi) - R - EXT;
+  const int rs = has_hi ? 2 * base_hi : base_lo;  // first position of the run
+  const int nr = has_hi ? NR : NS;
+  // where level i's window starts inside the run: R + EXT or one more; coordinates so large that the integer
+  // conversion saturates break that relation, and then every tap is outside the image anyway
+  const int off_lo = min(max(base_lo - rs, 0), nr - NS);
+  float* mywin = &win[wave][li][0];
 
-    // union of the 16 pixels' windows (all 64 lanes take part; the 4 groups hold copies)
-    int lo = live ? base : (1 << 30), hi = live ? base + NS - 1 : -(1 << 30);
+  // union of the 16 pixels' runs (all 64 lanes take part; the 4 groups hold copies)
+  int lo = live ? rs : (1 << 30), hi = live ? rs + nr - 1 : -(1 << 30);
 #pragma unroll
-    for (int o = 1; o < 16; o <<= 1) {
-      lo = min(lo, __shfl_xor(lo, o));
-      hi = max(hi, __shfl_xor(hi, o));
-    }
-    lo = max(lo, 0);
-    hi = min(hi, Wi - 1);
+  for (int o = 1; o < 16; o <<= 1) {
+    lo = min(lo, __shfl_xor(lo, o));
+    hi = max(hi, __shfl_xor(hi, o));
+  }
+  lo = max(lo, 0);
+  hi = min(hi, Wlo - 1);
 
-    const T* f2l = f2t + lay.f2_offset[i] + ((int64_t)bh * ((Wi + 15) >> 4)) * blk_elems + lane * EL;
-    // the next block of positions is requested before the current one is multiplied (the trip count is 1-3 and
-    // not known to the compiler, which otherwise exposes one memory latency per block)
-    const int cb_end = __builtin_amdgcn_readfirstlane(hi >> 4);
-    int cb = __builtin_amdgcn_readfirstlane(lo >> 4);
-    uint4 av[NKC], nx[NKC];
-    auto fetch = [&](uint4 (&dstv)[NKC], int blk) {
-      const T* ap = f2l + blk * blk_elems;
+  const T* f2l = f2t + lay.f2_offset[i] + ((int64_t)bh * ((Wlo + 15) >> 4)) * blk_elems + lane * EL;
+  // the next block of positions is requested before the current one is multiplied (the trip count is 2-4 and
+  // not known to the compiler, which otherwise exposes one memory latency per block)
+  const int cb_end = __builtin_amdgcn_readfirstlane(hi >> 4);
+  int cb = __builtin_amdgcn_readfirstlane(lo >> 4);
+  uint4 av[NKC], nx[NKC];
+  auto fetch = [&](uint4 (&dstv)[NKC], int blk) {
+    const T* ap = f2l + blk * blk_elems;
 #pragma unroll
-      for (int kc = 0; kc < NKC; ++kc)
-        if (FULL || kc < nkc) dstv[kc] = *reinterpret_cast<const uint4*>(ap + kc * 64 * EL);
-    };
-    // 16 right-image positions x 16 pixels on the matrix cores
-    auto multiply = [&](const uint4 (&a)[NKC], int blk) {
-      f4v acc = (f4v)(0.f);
+    for (int kc = 0; kc < NKC; ++kc)
+      if (FULL || kc < nkc) dstv[kc] = *reinterpret_cast<const uint4*>(ap + kc * 64 * EL);
+  };
+  // 16 right-image positions x 16 pixels on the matrix cores
+  auto multiply = [&](const uint4 (&a)[NKC], int blk) {
+    f4v acc = (f4v)(0.f);
 #pragma unroll
-      for (int kc = 0; kc < NKC; ++kc) {
-        if (FULL || kc < nkc) {
-          if constexpr (IS16) {
-            acc = mfma16<T>(__builtin_bit_cast(s8v, a[kc]), __builtin_bit_cast(s8v, bfrag[kc]), acc);
-          } else {
-            const f4v a4 = __builtin_bit_cast(f4v, a[kc]), b4 = __builtin_bit_cast(f4v, bfrag[kc]);
+    for (int kc = 0; kc < NKC; ++kc) {
+      if (FULL || kc < nkc) {
+        if constexpr (IS16) {
+          acc = mfma16<T>(__builtin_bit_cast(s8v, a[kc]), __builtin_bit_cast(s8v, bfrag[kc]), acc);
+        } else {
+          const f4v a4 = __builtin_bit_cast(f4v, a[kc]), b4 = __builtin_bit_cast(f4v, bfrag[kc]);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[e], b4[e], acc, 0, 0, 0);
-          }
+          for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[e], b4[e], acc, 0, 0, 0);
         }
       }
-      // lane holds C[w2 = blk*16 + 4g + r][this pixel]: keep what falls into the pixel's own window
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int w2 = blk * 16 + 4 * g + r;
-        const int j = w2 - base;
-        if ((unsigned)j < (unsigned)NS && w2 < Wi) mywin[j] = acc[r];
-      }
-    };
-    if constexpr (!IS16) {  // f32 operands are twice the registers: one block at a time
-      for (; cb <= cb_end; ++cb) {
-        fetch(av, cb);
-        multiply(av, cb);
-      }
-    } else if (cb <= cb_end) {  // (nothing to do when lo > hi)
-      fetch(av, cb);
-      while (true) {  // two register sets take turns: no copies
-        if (cb < cb_end) fetch(nx, cb + 1);
-        multiply(av, cb);
-        if (++cb > cb_end) break;
-        if (cb < cb_end) fetch(av, cb + 1);
-        multiply(nx, cb);
-        if (++cb > cb_end) break;
-      }
     }
-    // the four lane groups of a pixel exchange through LDS: one wave, in-order LDS, no workgroup barrier
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-    // lane group g interpolates taps g, g+4, g+8, ...; a tap position outside the image counts 0
+    // lane holds C[w2 = blk*16 + 4g + r][this pixel]: keep what falls into the pixel's own run
 #pragma unroll
-    for (int k0 = 0; k0 < NT; k0 += 4) {
-      const int k = k0 + g;
+    for (int r = 0; r < 4; ++r) {
+      const int w2 = blk * 16 + 4 * g + r;
+      const int j = w2 - rs;
+      if ((unsigned)j < (unsigned)nr && w2 < Wlo) mywin[j] = acc[r];
+    }
+  };
+  if constexpr (!IS16) {  // f32 operands are twice the registers: one block at a time
+    for (; cb <= cb_end; ++cb) {
+      fetch(av, cb);
+      multiply(av, cb);
+    }
+  } else if (cb <= cb_end) {  // (nothing to do when lo > hi)
+    fetch(av, cb);
+    while (true) {  // two register sets take turns: no copies
+      if (cb < cb_end) fetch(nx, cb + 1);
+      multiply(av, cb);
+      if (++cb > cb_end) break;
+      if (cb < cb_end) fetch(av, cb + 1);
+      multiply(nx, cb);
+      if (++cb > cb_end) break;
+    }
+  }
+  // the four lane groups of a pixel exchange through LDS: one wave, in-order LDS, no workgroup barrier
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  // lane group g interpolates taps g, g+4, g+8, ... of both levels; a tap position outside the image counts 0
+  float* orow = out + ((int64_t)b * lay.L * NT) * HW + (int64_t)h * lay.W1 + w1c;
+#pragma unroll
+  for (int k0 = 0; k0 < NT; k0 += 4) {
+    const int k = k0 + g;
+    {  // level i: slots off_lo ..
       int t0;
       float wa, wb;
       if (MODE == RC_COORD_EXACT) {
-        t0 = base + k;
-        wb = xi - xf;
+        t0 = base_lo + k;
+        wb = x_lo - f_lo;
         wa = 1.0f - wb;
       } else {
-        rc_gridsample_coords(xi, k - R, (float)(Wi - 1), &t0, &wa, &wb);
+        rc_gridsample_coords(x_lo, k - R, (float)(Wlo - 1), &t0, &wa, &wb);
       }
-      const int j0 = min(max(t0 - base, 0), NS - 2);
+      const int j0 = off_lo + min(max(t0 - base_lo, 0), NS - 2);
       const float v0 = mywin[j0], v1 = mywin[j0 + 1];
-      const float s = ((unsigned)t0 < (unsigned)Wi ? wa * v0 : 0.f) + ((unsigned)(t0 + 1) < (unsigned)Wi ? wb * v1 : 0.f);
-      if (live && k < NT) out[((int64_t)b * lay.L * NT + i * NT + k) * HW + (int64_t)h * lay.W1 + w1] = s * scale;
+      const float s = ((unsigned)t0 < (unsigned)Wlo ? wa * v0 : 0.f) + ((unsigned)(t0 + 1) < (unsigned)Wlo ? wb * v1 : 0.f);
+      if (live && k < NT) orow[(int64_t)(i * NT + k) * HW] = s * scale;
+    }
+    if (has_hi) {  // level i + 1: slot pairs (2j, 2j + 1) of the run
+      int t0;
+      float wa, wb;
+      if (MODE == RC_COORD_EXACT) {
+        t0 = base_hi + k;
+        wb = x_hi - f_hi;
+        wa = 1.0f - wb;
+      } else {
+        rc_gridsample_coords(x_hi, k - R, (float)(Whi - 1), &t0, &wa, &wb);
+      }
+      const int j0 = 2 * min(max(t0 - base_hi, 0), NS - 2);
+      const float v0 = 0.5f * (mywin[j0] + mywin[j0 + 1]), v1 = 0.5f * (mywin[j0 + 2] + mywin[j0 + 3]);
+      const float s = ((unsigned)t0 < (unsigned)Whi ? wa * v0 : 0.f) + ((unsigned)(t0 + 1) < (unsigned)Whi ? wb * v1 : 0.f);
+      if (live && k < NT) orow[(int64_t)((i + 1) * NT + k) * HW] = s * scale;
     }
   }
 }
@@ -269,7 +299,7 @@ __global__ __launch_bounds__(256) void alt_fwd_kernel(const T* __restrict__ f1t,
 template <typename T, int R>
 int launch_alt(const void* f1t, const void* f2t, const alt_dev_layout& d, const float* coords, int cc,
                float* out, int mode, hipStream_t st) {
-  const int bpr = (d.W1 + 15) / 16;
+  const int bpr = (d.W1 + 31) / 32;  // workgroups per image row: 32 pixels each
   const int n_rows = d.B * d.H;
   const int64_t nb = (int64_t)((n_rows + 7) / 8) * 8 * bpr;
   RC_REQUIRE(nb < (1ll << 31), RC_EINVAL, "too many pixels");
