@@ -261,17 +261,19 @@ int rc_sampler_bwd(const float* coords, int coords_channels, const void* corr_gr
 /*
  * On-the-fly ("alt") correlation.  rc_alt_prepare converts the feature maps once per image
  * pair into channel-last working copies: f1t [B,H,W1,Dp] and the pooled f2 pyramid
- * f2t level i [B,H,W2>>i,Dp] (Dp = D rounded up to 32, zero padded), both of `in_dtype`.
- * rc_alt_fwd then computes the same [B, L*(2r+1), H, W1] float output as rc_lookup_fwd from
- * banded MFMA products, without ever materialising the volume.
+ * f2t level i [B,H,W2>>i,Dp] for the EVEN levels i (Dp = D rounded up to 32, zero padded),
+ * both of `in_dtype`.  rc_alt_fwd then computes the same [B, L*(2r+1), H, W1] float output as
+ * rc_lookup_fwd from banded MFMA products, without ever materialising the volume; an odd
+ * level's correlations are the means of two of the level below (pooling is linear), so the
+ * odd levels of f2 have no copy (f2_offset 0, nothing counted in f2_elems).
  */
 typedef struct rc_alt_layout {
   int64_t B, H, W1, W2, D, Dp;
   int32_t L;
   int32_t width[RC_MAX_LEVELS];
   int64_t f1_elems;                 /* elements of f1t */
-  int64_t f2_offset[RC_MAX_LEVELS]; /* element offset of level i inside f2t */
-  int64_t f2_elems;                 /* elements of the whole f2t pyramid */
+  int64_t f2_offset[RC_MAX_LEVELS]; /* element offset of (even) level i inside f2t */
+  int64_t f2_elems;                 /* elements of f2t: its even levels */
 } rc_alt_layout;
 
 int rc_alt_layout_init(int64_t B, int64_t D, int64_t H, int64_t W1, int64_t W2, int L,

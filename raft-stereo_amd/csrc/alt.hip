@@ -59,7 +59,7 @@ alt_dev_layout to_dev(const rc_alt_layout* a) {
 struct frag_levels {
   int nlev;
   int width[RC_MAX_LEVELS];
-  int64_t offset[RC_MAX_LEVELS];
+  int64_t offset[RC_MAX_LEVELS];  // < 0: the level is only a step of the pooling chain and is not written
 };
 
 template <typename T>
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void to_fragments_kernel(const T* __restrict__
     const int Wl = lv.width[i], nblk = (Wl + 15) >> 4;
     const int blocks_here = 8 >> i;  // 16-position blocks of this level inside the tile
     T* base = dst + lv.offset[i];
-    for (int f = threadIdx.x; f < blocks_here * KPT * 64; f += 256) {
+    for (int f = threadIdx.x; lv.offset[i] >= 0 && f < blocks_here * KPT * 64; f += 256) {
       const int li = f & 15, g = (f >> 4) & 3, kcl = (f >> 6) % KPT, blk = (f >> 6) / KPT;
       const int pb = (w0 >> (4 + i)) + blk, kc = d0 / KCH + kcl;
       if (pb >= nblk || kc >= nkc) continue;
@@ -356,10 +356,10 @@ int run_prepare(const void* f1, const void* f2, void* f1t, void* f2t, const rc_a
   int rc = rc_check_launch("rc_alt_prepare(f1)");
   if (rc) return rc;
   frag_levels all = {};
-  all.nlev = a->L;
-  for (int i = 0; i < a->L; ++i) {
+  all.nlev = ((a->L - 1) & ~1) + 1;  // the last level that has a copy
+  for (int i = 0; i < all.nlev; ++i) {
     all.width[i] = a->width[i];
-    all.offset[i] = a->f2_offset[i];
+    all.offset[i] = (i & 1) ? -1 : a->f2_offset[i];
   }
   hipLaunchKernelGGL((to_fragments_kernel<T>), dim3((unsigned)((a->W2 + 127) / 128), (Dp + 63) / 64, BH), dim3(256),
                      0, st, (const T*)f2, (T*)f2t, D, Dp, H, (int)a->W2, all);
@@ -383,6 +383,7 @@ extern "C" int rc_alt_layout_init(int64_t B, int64_t D, int64_t H, int64_t W1, i
   int64_t off = 0;
   for (int i = 0; i < L; ++i) {
     out->width[i] = (int32_t)(W2 >> i);
+    if (i & 1) continue;  // odd levels have no copy: the lookup derives them from the level below (offset 0)
     out->f2_offset[i] = off;
     off += B * H * (int64_t)((out->width[i] + 15) / 16 * 16) * out->Dp;
   }
