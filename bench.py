@@ -216,6 +216,42 @@ def fused_convc1(step, cfg, device, n=50):
                 fused_lookup_convc1_gbps=round(alg / (fused * 1e-6) / 1e9, 1))
 
 
+def sampler_twin(cfg, device, n=50):
+    """SURVEY 8(a) rows a6/a7 as the reference ships them: the `corr_sampler` extension's forward and backward on
+    the caller's own row-major level-0 volume [B,H,W1,W2] (sampler/sampler_kernel.cu:19-166), measured beside
+    the contract's metric.  Algorithmic bytes: forward reads 2r+2 volume entries and one coordinate per pixel
+    and writes 2r+1 values; backward writes the whole zero-filled gradient volume (the reference allocates
+    zeros_like and adds 2r+2 entries per pixel, :148) and reads 2r+1 gradients and one coordinate per pixel."""
+    from raft_stereo_amd import sampler
+    dt = DTYPES[cfg["dtype"]]
+    s = 4 if cfg["dtype"] == "f32" else 2
+    B, H, W = cfg["batch"], cfg["H"], cfg["W"]
+    g = torch.Generator(device=device).manual_seed(123)
+    vol = torch.randn((B, H, W, W), generator=g, device=device).to(dt)
+    coords = torch.from_numpy(synthetic_coords(B, H, W, seed=11)).to(device)
+    nt = 2 * RADIUS + 1
+    gcorr = torch.randn((B, nt, H, W), generator=g, device=device).to(dt)
+
+    def timed(fn):
+        for _ in range(5):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            fn()
+        b.record()
+        b.synchronize()
+        return a.elapsed_time(b) / n * 1e3
+
+    fwd = timed(lambda: sampler.forward(vol, coords, RADIUS))
+    bwd = timed(lambda: sampler.backward(vol, coords, gcorr, RADIUS))
+    px = B * H * W
+    fwd_bytes = px * ((nt + 1) * s + 4 + nt * s)
+    bwd_bytes = px * (W * s + nt * s + 4)
+    return dict(sampler_twin_fwd_us=round(fwd, 2), sampler_twin_fwd_gbps=round(fwd_bytes / (fwd * 1e-6) / 1e9, 1),
+                sampler_twin_bwd_us=round(bwd, 2), sampler_twin_bwd_gbps=round(bwd_bytes / (bwd * 1e-6) / 1e9, 1))
+
+
 def update_ops(cfg, device, n=50):
     """SURVEY 8(f) ranks 3 and 4, measured beside the contract's metric: the ConvGRU gate arithmetic on the
     1/f-resolution hidden state ([B,128,H,W], core/update.py:27-31) as two library kernels against the same
@@ -850,6 +886,8 @@ def main():
             extra.update(refine_loop(step, cfg, device, capture=False, baseline=False))
     elif not is_alt and not cfg["train"] and rank == 0:
         extra.update(fused_convc1(step, cfg, device))      # after the timed region: not part of `value`
+        if cfg["H"] * cfg["W"] * cfg["W"] * cfg["batch"] <= (1 << 28):
+            extra.update(sampler_twin(cfg, device))
     if not args.loop_only and rank == 0 and cfg["H"] * cfg["W"] * cfg["batch"] <= 300000:
         extra.update(update_ops(cfg, device))              # side metrics, after the timed region
     if (not args.loop_only and not cfg["train"] and rank == 0 and cfg["H"] * cfg["W"] * cfg["batch"] <= 300000

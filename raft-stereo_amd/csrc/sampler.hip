@@ -1,56 +1,118 @@
 // Drop-in kernels for the reference's `corr_sampler` extension (sampler/sampler.cpp:24-51,
 // sampler/sampler_kernel.cu:19-166): one level, the CALLER's row-major volume [B,H,W1,W2].
 //
-// The row-major layout is part of that interface, so a pixel's 2r+2 taps are contiguous while
-// neighbouring pixels are a whole volume row apart.  Instead of one thread per pixel (10 strided
-// scalar loads each) a quarter-wave of 16 lanes serves one pixel: lane j < 2r+2 loads tap j, so
-// every load instruction of the wave fetches four contiguous 2r+2-element windows, and the
-// lerp pairs are exchanged with a DPP-style shuffle.  The arithmetic follows the reference:
-// products and sums are rounded to the volume's type (sampler_kernel.cu:50-56, :94-102).
+// The row-major layout is part of that interface: a pixel's 2r+2 taps are contiguous while neighbouring
+// pixels are a whole volume row apart, so every pixel costs one or two cache lines whatever the kernel does.
+// Forward: one pixel per lane (2r+2 predicated element loads, the outputs leave coalesced per channel plane);
+// a quarter-wave per pixel, round 1's shape, made sixteen times the waves for the same lines (14.8 us at the
+// KITTI size against 6).  Backward: the gradient volume is written exactly once, as a stream of 16-byte
+// pieces (a lane owns 8 or 4 consecutive entries of the flat array, zero unless the pixel's window crosses
+// them): the reference zero-fills it and then adds 2r+2 entries per pixel (sampler_kernel.cu:148, :102).
+// The arithmetic follows the reference: products and sums are rounded to the volume's type
+// (sampler_kernel.cu:50-56, :94-102).
 #include "rc_common.h"
 
 namespace {
 
 constexpr int SP_THREADS = 256;
+constexpr int SP_MAXTAPS = 2 * RC_SAMPLER_MAX_RADIUS + 2;
 
-template <typename T>
+template <typename T, int R>
 __global__ __launch_bounds__(SP_THREADS) void sampler_fwd_kernel(const T* __restrict__ volume,
                                                                  const float* __restrict__ coords,
                                                                  int coords_channels, T* __restrict__ corr,
-                                                                 int B, int H, int W1, int W2, int r,
-                                                                 int64_t n_pix) {
-  const int64_t pix = ((int64_t)blockIdx.x * SP_THREADS + threadIdx.x) >> 4;
-  const int j = threadIdx.x & 15;  // tap index served by this lane
-  const bool live = pix < n_pix;
-  const int64_t p = live ? pix : 0;
-  const int x = (int)(p % W1);
-  const int64_t t = p / W1;
-  const int y = (int)(t % H);
-  const int n = (int)(t / H);
+                                                                 int H, int W1, int W2, int64_t n_pix) {
+  const int64_t pix = (int64_t)blockIdx.x * SP_THREADS + threadIdx.x;
+  if (pix >= n_pix) return;
   const int64_t HW = (int64_t)H * W1;
-
-  const float x0 = coords[((int64_t)n * coords_channels) * HW + (int64_t)y * W1 + x];
+  const int64_t n = pix / HW, q = pix - n * HW;  // image, pixel inside it
+  const float x0 = coords[(n * coords_channels) * HW + q];
   const float fx = floorf(x0);
   const float dx = x0 - fx;
-  const int x1 = rc_safe_int(fx) - r + j;
-  const int rd = 2 * r + 1;
-  float s = 0.f;
-  if (live && j <= rd && (unsigned)x1 < (unsigned)W2) s = rc_to_float(volume[(p * W2) + x1]);
+  const int base = rc_safe_int(fx) - R;
+  constexpr int rd = 2 * R + 1;
+  const T* row = volume + pix * W2;
+  float sv[rd + 1];
+#pragma unroll
+  for (int j = 0; j <= rd; ++j) {
+    const int x1 = base + j;
+    sv[j] = (unsigned)x1 < (unsigned)W2 ? rc_to_float(row[x1]) : 0.f;
+  }
   // corr[j] = s_j * (1 - dx) + s_{j+1} * dx, each product and the sum rounded to T
-  const float a = rc_round_as<T>(s * rc_round_as<T>(1.0f - dx));
-  const float snext = __shfl_down(s, 1, 16);
-  const float bq = rc_round_as<T>(snext * rc_round_as<T>(dx));
-  if (live && j < rd) corr[(((int64_t)n * rd + j) * H + y) * W1 + x] = rc_from_float<T>(a + bq);
+  const float wa = rc_round_as<T>(1.0f - dx), wb = rc_round_as<T>(dx);
+  T* o = corr + (n * rd) * HW + q;
+#pragma unroll
+  for (int j = 0; j < rd; ++j)
+    o[(int64_t)j * HW] = rc_from_float<T>(rc_round_as<T>(sv[j] * wa) + rc_round_as<T>(sv[j + 1] * wb));
 }
 
+// W2 % VEC == 0 (VEC entries = 16 bytes): a wave writes SP_RPW whole pixel rows, one 16-byte piece per lane and
+// row (rows longer than 64 pieces take more turns); the pixel's coordinate is one address for the whole wave,
+// and nothing is divided per lane (a flat piece index per lane cost two 64-bit divisions for 16 bytes of
+// output: 86 us at the KITTI size against 66 for element stores)
+constexpr int SP_RPW = 8;
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(SP_THREADS) void sampler_bwd_vec_kernel(const float* __restrict__ coords,
+                                                                     int coords_channels,
+                                                                     const T* __restrict__ corr_grad,
+                                                                     T* __restrict__ volume_grad, int HW, int W2,
+                                                                     int r, uint32_t n_pix) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (SP_THREADS / 64) + (threadIdx.x >> 6));
+  const uint32_t pix0 = wave * SP_RPW;
+  if (pix0 >= n_pix) return;
+  const int ppr = W2 / VEC;  // pieces per pixel row
+  const int rd = 2 * r + 1;
+  uint32_t n = pix0 / (uint32_t)HW, q = pix0 - n * (uint32_t)HW;  // wave-uniform
+  typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+  float xs[SP_RPW], gs[SP_RPW];
+#pragma unroll
+  for (int k = 0; k < SP_RPW; ++k) {  // the rows' coordinates and gradients first: 2 SP_RPW loads in flight
+    const bool have = pix0 + k < n_pix;  // wave-uniform
+    xs[k] = have ? coords[((int64_t)n * coords_channels) * HW + q] : 0.f;
+    // lane j < 2r+1 holds the pixel's gradient of tap j
+    gs[k] = have && lane < rd ? rc_to_float(corr_grad[((int64_t)n * rd + lane) * HW + q]) : 0.f;
+    if (++q == (uint32_t)HW) {
+      q = 0;
+      ++n;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < SP_RPW; ++k) {
+    if (pix0 + k >= n_pix) break;  // wave-uniform
+    const float fx = floorf(xs[k]);
+    const float dx = xs[k] - fx;
+    const int base = rc_safe_int(fx) - r;
+    const float wa = rc_round_as<T>(1.0f - dx), wb = rc_round_as<T>(dx);
+    // lane j <= 2r+1: what column base + j receives (sampler_kernel.cu:94-102, the same order of additions)
+    const float gprev = __shfl_up(gs[k], 1);
+    float acc = 0.f;
+    if (lane > 0 && lane <= rd) acc = rc_round_as<T>(acc + rc_round_as<T>(gprev * wb));
+    if (lane < rd) acc = rc_round_as<T>(acc + rc_round_as<T>(gs[k] * wa));
+    T* row = volume_grad + (int64_t)(pix0 + k) * W2;
+    for (int p0 = 0; p0 < ppr; p0 += 64) {  // every lane takes every turn: the exchanges below need lanes 0..2r+1
+      const int w0 = (p0 + lane) * VEC;
+      alignas(16) T v[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const int j = w0 + e - base;  // tap index that lands on this column
+        const float t = __shfl(acc, j & 63);
+        v[e] = rc_from_float<T>((unsigned)j <= (unsigned)rd ? t : 0.f);
+      }
+      if (p0 + lane < ppr)
+        __builtin_nontemporal_store(*reinterpret_cast<const u4*>(v), reinterpret_cast<u4*>(row + w0));
+    }
+  }
+}
+
+// any W2: one wave per pixel row, element stores
 template <typename T>
 __global__ __launch_bounds__(SP_THREADS) void sampler_bwd_kernel(const float* __restrict__ coords,
                                                                  int coords_channels,
                                                                  const T* __restrict__ corr_grad,
                                                                  T* __restrict__ volume_grad, int B, int H,
                                                                  int W1, int W2, int r, int64_t n_pix) {
-  // one wave per pixel row of the volume: zero-fills the row (the reference allocates a fresh
-  // zeros_like, sampler_kernel.cu:148) and drops the 2r+2 tap gradients in.
   const int lane = threadIdx.x & 63;
   const int64_t pix = ((int64_t)blockIdx.x * SP_THREADS + threadIdx.x) >> 6;
   if (pix >= n_pix) return;
@@ -97,13 +159,21 @@ extern "C" int rc_sampler_fwd(const void* volume, const float* coords, int coord
   int rc = check_args(volume, coords, corr, coords_channels, B, H, W1, W2, radius);
   if (rc) return rc;
   const int64_t n_pix = B * H * W1;
-  const unsigned blocks = (unsigned)((n_pix * 16 + SP_THREADS - 1) / SP_THREADS);
+  const unsigned blocks = (unsigned)((n_pix + SP_THREADS - 1) / SP_THREADS);
   hipStream_t st = (hipStream_t)stream;
-#define RC_CASE(ID, T)                                                                                   \
-  case ID:                                                                                               \
-    hipLaunchKernelGGL((sampler_fwd_kernel<T>), dim3(blocks), dim3(SP_THREADS), 0, st, (const T*)volume, \
-                       coords, coords_channels, (T*)corr, (int)B, (int)H, (int)W1, (int)W2, radius, n_pix); \
+#define RC_CASE_R(T, RR)                                                                                       \
+  case RR:                                                                                                     \
+    hipLaunchKernelGGL((sampler_fwd_kernel<T, RR>), dim3(blocks), dim3(SP_THREADS), 0, st, (const T*)volume,   \
+                       coords, coords_channels, (T*)corr, (int)H, (int)W1, (int)W2, n_pix);                    \
     break;
+#define RC_CASE(ID, T)                                                                                         \
+  case ID:                                                                                                     \
+    switch (radius) {                                                                                          \
+      RC_CASE_R(T, 1) RC_CASE_R(T, 2) RC_CASE_R(T, 3) RC_CASE_R(T, 4) RC_CASE_R(T, 5) RC_CASE_R(T, 6)         \
+      RC_CASE_R(T, 7)                                                                                          \
+    }                                                                                                          \
+    break;
+  static_assert(RC_SAMPLER_MAX_RADIUS == 7, "one case per radius");
   switch (dtype) {
     RC_CASE(RC_F32, float)
     RC_CASE(RC_F16, rc_half)
@@ -113,6 +183,7 @@ extern "C" int rc_sampler_fwd(const void* volume, const float* coords, int coord
       return RC_EUNSUPPORTED;
   }
 #undef RC_CASE
+#undef RC_CASE_R
   return rc_check_launch("rc_sampler_fwd");
 }
 
@@ -122,13 +193,22 @@ extern "C" int rc_sampler_bwd(const float* coords, int coords_channels, const vo
   int rc = check_args(coords, corr_grad, volume_grad, coords_channels, B, H, W1, W2, radius);
   if (rc) return rc;
   const int64_t n_pix = B * H * W1;
-  const unsigned blocks = (unsigned)((n_pix * 64 + SP_THREADS - 1) / SP_THREADS);
   hipStream_t st = (hipStream_t)stream;
-#define RC_CASE(ID, T)                                                                                  \
-  case ID:                                                                                              \
-    hipLaunchKernelGGL((sampler_bwd_kernel<T>), dim3(blocks), dim3(SP_THREADS), 0, st, coords,          \
-                       coords_channels, (const T*)corr_grad, (T*)volume_grad, (int)B, (int)H, (int)W1,  \
-                       (int)W2, radius, n_pix);                                                         \
+  const int esz = dtype == RC_F32 ? 4 : 2, vec = 16 / esz;
+  const bool vector = W2 % vec == 0 && (uintptr_t)volume_grad % 16 == 0 && n_pix < (1ll << 31) && H * W1 < (1ll << 31);
+  const int64_t n_waves = (n_pix + SP_RPW - 1) / SP_RPW;
+  const unsigned blocks = vector ? (unsigned)((n_waves * 64 + SP_THREADS - 1) / SP_THREADS)
+                                 : (unsigned)((n_pix * 64 + SP_THREADS - 1) / SP_THREADS);
+#define RC_CASE(ID, T)                                                                                         \
+  case ID:                                                                                                     \
+    if (vector)                                                                                                \
+      hipLaunchKernelGGL((sampler_bwd_vec_kernel<T, 16 / (int)sizeof(T)>), dim3(blocks), dim3(SP_THREADS), 0,  \
+                         st, coords, coords_channels, (const T*)corr_grad, (T*)volume_grad, (int)(H * W1),     \
+                         (int)W2, radius, (uint32_t)n_pix);                                                    \
+    else                                                                                                       \
+      hipLaunchKernelGGL((sampler_bwd_kernel<T>), dim3(blocks), dim3(SP_THREADS), 0, st, coords,               \
+                         coords_channels, (const T*)corr_grad, (T*)volume_grad, (int)B, (int)H, (int)W1,       \
+                         (int)W2, radius, n_pix);                                                              \
     break;
   switch (dtype) {
     RC_CASE(RC_F32, float)
