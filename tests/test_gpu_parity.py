@@ -261,6 +261,38 @@ def test_sampler_twin_16bit_rounds_like_scalar_t(R, golden, case, kind, dtype):
         assert np.array_equal(gv.float().cpu().numpy(), rg), float(np.abs(gv.float().cpu().numpy() - rg).max())
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape,r", [((2, 3, 7, 1040), 4), ((3, 5, 5, 312), 7), ((1, 2, 9, 72), 1),
+                                      ((2, 3, 7, 44), 3)])
+def test_sampler_twin_long_rows_and_waves_across_images(R, shape, r, dtype):
+    """The backward's vector kernel: rows longer than one wave turn (W2 = 1040: 130 or 260 pieces), waves of 8
+    pixel rows that straddle two images (H*W1 = 21, 25), the smallest and the largest radius, coordinates that
+    put windows partly and wholly outside the row; W2 = 44 takes the element-store kernel for 16-bit types.
+    Both directions against the scalar_t-rounding oracle, bit for bit for the 16-bit types."""
+    B, H, W1, W2 = shape
+    rng = np.random.default_rng(1000 + W2 + r)
+    vol = dev(rng.standard_normal(shape).astype(np.float32), dtype)
+    coords = np.zeros((B, 2, H, W1), np.float32)
+    coords[:, 0] = rng.uniform(-2 * r - 3, W2 + 2 * r + 3, size=(B, H, W1)).astype(np.float32)
+    coords[:, 0, 0, 0] = 0.0            # integer coordinates: dx = 0
+    coords[:, 0, -1, -1] = W2 - 1.0
+    gout = dev(rng.standard_normal((B, 2 * r + 1, H, W1)).astype(np.float32), dtype)
+    if dtype == torch.float32:
+        rnd = lambda a: np.asarray(a, np.float32)
+    elif dtype == torch.float16:
+        rnd = lambda a: np.asarray(a, np.float32).astype(np.float16).astype(np.float32)
+    else:
+        rnd = O.round_bf16
+    # fp32: a product and the following sum may be one fused multiply-add (in the reference's kernel as well)
+    same = (lambda a, b: np.allclose(a, b, rtol=1e-6, atol=1e-6)) if dtype == torch.float32 else np.array_equal
+    out, = R.corr_sampler_hip.forward(vol, dev(coords), r)
+    ref = O.sampler_fwd_rounded(vol.float().cpu().numpy(), coords, r, rnd)
+    assert same(out.float().cpu().numpy(), ref)
+    gv, = R.corr_sampler_hip.backward(vol, dev(coords), gout, r)
+    rg = O.sampler_bwd_rounded(coords, gout.float().cpu().numpy(), W2, r, rnd)
+    assert same(gv.float().cpu().numpy(), rg)
+
+
 def test_sampler_twin_argument_checks(R):
     """sampler.cpp:20-22 CHECK_INPUT and the accessor types (packed_accessor32<float,4> for coords) raise on a
     wrong dtype or shape; the twin must not launch on them either."""
