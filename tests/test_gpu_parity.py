@@ -104,6 +104,33 @@ def test_alt_fp32_matches_reference_reg(R, golden, case, kind):
     assert rel(out, g[f"alt_{kind}"]) < 5e-5
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("levels,radius,shape", [(1, 4, (2, 64, 3, 50, 50)), (2, 1, (1, 32, 2, 37, 61)),
+                                                  (3, 6, (1, 96, 2, 90, 77)), (4, 4, (2, 256, 2, 75, 75)),
+                                                  (3, 2, (1, 64, 1, 17, 40))])
+def test_alt_equals_reg_every_level_count(R, dtype, levels, radius, shape):
+    """alt_hip serves levels in pairs from the even levels' copies of f2 (an odd level's correlations are the
+    means of two of the level below); reg_hip reads the materialised pyramid.  Same function of the inputs at
+    every level count (a last level that stands alone included), odd widths, W1 != W2, coordinates far outside
+    the image, both coordinate modes."""
+    B, D, H, W1, W2 = shape
+    gen = torch.Generator(device="cuda").manual_seed(levels * 100 + radius)
+    f1 = torch.randn((B, D, H, W1), generator=gen, device="cuda").to(dtype)
+    f2 = torch.randn((B, D, H, W2), generator=gen, device="cuda").to(dtype)
+    coords = torch.zeros((B, 2, H, W1), device="cuda")
+    coords[:, 0] = torch.rand((B, H, W1), generator=gen, device="cuda") * (W2 + 30) - 15
+    coords[:, 0, 0, 0] = -1e4
+    coords[:, 0, -1, -1] = 3e9
+    coords[:, 0, 0, 1] = 7.0
+    for mode in ("exact", "gridsample"):
+        with torch.no_grad():
+            reg = R.CorrBlock1DHip(f1, f2, num_levels=levels, radius=radius, coord_mode=mode,
+                                   volume_dtype=torch.float32)(coords)
+            alt = R.AltCorrBlock1DHip(f1, f2, num_levels=levels, radius=radius, coord_mode=mode)(coords)
+        assert alt.shape == reg.shape == (B, levels * (2 * radius + 1), H, W1)
+        assert rel(alt, reg.cpu().numpy()) < (2e-5 if dtype == torch.float32 else 2e-3)
+
+
 @pytest.mark.parametrize("case", GOLDEN_CASES)
 def test_alt_backward_fp32_matches_reference_autograd(R, golden, case):
     """alt_hip is the same function of the feature maps as reg, so the reference's autograd
