@@ -55,6 +55,10 @@ def note(msg):
 
 
 _T0 = time.perf_counter()
+if os.environ.get("RC_BENCH_DUMP_AFTER"):
+    # a hang names itself: every thread's Python stack on stderr after N seconds, then exit
+    import faulthandler
+    faulthandler.dump_traceback_later(float(os.environ["RC_BENCH_DUMP_AFTER"]), exit=True)
 
 
 def synthetic_coords(B, H, W, seed=1234, adversarial=False):
@@ -581,9 +585,11 @@ def refine_train_step(step, cfg, device, reps=2, dist=None):
     model = Refiner(blk)
     if world > 1:
         from torch.nn.parallel import DistributedDataParallel
-        # the default 25 MB buckets, all-reduced while the backward pass is still running.  (Gradients are
-        # copied into the buckets: with gradient_as_bucket_view=True the second step's backward pass stalled in
-        # the 2-rank rehearsal.)
+        # the default 25 MB buckets, all-reduced while the backward pass is still running.  (The rehearsal of
+        # this leg with two ranks on ONE GPU over gloo stalls in a backward pass, sooner or later, whatever the
+        # bucket options -- and so does plain torch DDP without a kernel of this library, on the second step:
+        # tools/lab_ddp_gloo_control.py.  CPU tensors over gloo are fine (tests/test_cpu_host.py); RCCL needs
+        # more than one GPU, which the boxes this was built on do not have.)
         model = DistributedDataParallel(model, device_ids=[device.index], gradient_as_bucket_view=False)
         note("update block wrapped in DistributedDataParallel")
         if os.environ.get("RC_BENCH_VERBOSE"):
