@@ -213,11 +213,22 @@ def fused_convc1(step, cfg, device, n=50):
 
         fused = timed(lambda: blk.lookup_convc1(step.coords, wgt, bias))
         unfused = timed(lambda: torch.relu_(torch.nn.functional.conv2d(blk(step.coords).to(dt), wq, bq)))
+        vt = None
+        if cfg["dtype"] != "f32" and step.cls is step.R.CorrBlock1DHip:
+            # the lookup with its taps in the volume's 16-bit type (rc_lookup_fwd_vt: what the reference's
+            # CorrBlockFast1D returns under mixed precision), coordinates moved every call like the timed region
+            blk16 = step.cls(step.f1, step.f2, num_levels=LEVELS, radius=RADIUS, out_dtype=dt)
+            it = iter(range(10 ** 9))
+            vt = timed(lambda: blk16(step.coords_list[next(it) % len(step.coords_list)]))
     px = cfg["batch"] * cfg["H"] * cfg["W"]
     s = 4 if cfg["dtype"] == "f32" else 2
     alg = px * (LEVELS * (2 * RADIUS + 2) * s + 4 + 64 * s)
-    return dict(fused_lookup_convc1_us=round(fused, 2), unfused_lookup_then_convc1_us=round(unfused, 2),
-                fused_lookup_convc1_gbps=round(alg / (fused * 1e-6) / 1e9, 1))
+    res = dict(fused_lookup_convc1_us=round(fused, 2), unfused_lookup_then_convc1_us=round(unfused, 2),
+               fused_lookup_convc1_gbps=round(alg / (fused * 1e-6) / 1e9, 1))
+    if vt is not None:
+        alg16 = px * (LEVELS * (2 * RADIUS + 2) * s + 4 + LEVELS * (2 * RADIUS + 1) * s)
+        res.update(lookup_16bit_out_us=round(vt, 2), lookup_16bit_out_gbps=round(alg16 / (vt * 1e-6) / 1e9, 1))
+    return res
 
 
 def sampler_twin(cfg, device, n=50):

@@ -146,6 +146,15 @@ int rc_build_pyramid_naive(const void* f1, const void* f2, void* vol, const rc_l
  */
 int rc_lookup_fwd(const void* vol, const rc_layout* lay, const float* coords,
                   int coords_channels, float* out, int radius, int coord_mode, void* stream);
+/*
+ * The same lookup with `out` in the VOLUME's type (lay->dtype; for an fp32 pyramid identical to
+ * rc_lookup_fwd): what the reference's mixed-precision block returns -- CorrBlockFast1D's
+ * CorrSampler allocates its result with volume.options() (core/corr.py:44-51,
+ * sampler/sampler_kernel.cu:122-124), fp16 under autocast, where CorrBlock1D ends in .float()
+ * (core/corr.py:146).  Every tap is computed in fp32 as in rc_lookup_fwd and rounded once.
+ */
+int rc_lookup_fwd_vt(const void* vol, const rc_layout* lay, const float* coords,
+                     int coords_channels, void* out, int radius, int coord_mode, void* stream);
 
 /*
  * SURVEY.md section 8(f) rank 2 -- the GRU iteration's coordinate glue folded into the lookup

@@ -58,6 +58,7 @@ SIGNATURES = {
     "rc_build_pyramid": (_I, [_P, _P, _P, _LP, _L, _I, _P]),
     "rc_build_pyramid_naive": (_I, [_P, _P, _P, _LP, _L, _I, _P]),
     "rc_lookup_fwd": (_I, [_P, _LP, _P, _I, _P, _I, _I, _P]),
+    "rc_lookup_fwd_vt": (_I, [_P, _LP, _P, _I, _P, _I, _I, _P]),
     "rc_lookup_fwd_update": (_I, [_P, _LP, _P, _I, _P, _P, _P, _P, _I, _I, _P]),
     "rc_lookup_bwd": (_I, [_P, _I, _P, _P, _LP, _I, _I, _P]),
     "rc_build_bwd_work_bytes": (_L, [_LP, _I]),

@@ -189,7 +189,7 @@ class _LookupConvc1Fn(torch.autograd.Function):
         block = ctx.block
         K = block.num_levels * (2 * block.radius + 1)
         dev = block.device
-        corr = block._lookup(coords)                          # recomputed: the forward never stored it
+        corr = block._lookup(coords, fp32=True)               # recomputed: the forward never stored it
         g = grad_act.to(act.dtype).contiguous()
         w32 = weight.detach().reshape(_lib.RC_CONVC1_OUT, K).float().contiguous()
         with torch.cuda.device(dev):
@@ -217,13 +217,19 @@ class CorrBlock1DHip:
     core/corr.py:29).
     """
 
-    def __init__(self, fmap1, fmap2, num_levels=4, radius=4, coord_mode=None, volume_dtype=None):
+    def __init__(self, fmap1, fmap2, num_levels=4, radius=4, coord_mode=None, volume_dtype=None, out_dtype=None):
         B, D, H, W1, W2 = _check_fmaps(fmap1, fmap2, num_levels, radius)
         self.num_levels, self.radius = num_levels, radius
         self.B, self.D, self.H, self.W1, self.W2 = B, D, H, W1, W2
         self.device = fmap1.device
         self.in_dtype = _DT[fmap1.dtype]
         self.volume_torch_dtype = volume_dtype or fmap1.dtype
+        # out_dtype: fp32 (default: what CorrBlock1D returns, core/corr.py:145-146) or the volume's own 16-bit
+        # type (what CorrBlockFast1D returns under mixed precision: CorrSampler allocates volume.options(),
+        # core/corr.py:44-51, sampler_kernel.cu:122-124) -- half the bytes the lookup writes
+        if out_dtype not in (None, torch.float32, self.volume_torch_dtype):
+            raise TypeError("out_dtype must be float32 or the volume's dtype")
+        self.out_torch_dtype = out_dtype or torch.float32
         if self.volume_torch_dtype not in (fmap1.dtype, torch.float32):
             raise TypeError("volume_dtype must be the feature dtype or float32")
         self.vol_dtype = _DT[self.volume_torch_dtype]
@@ -255,13 +261,16 @@ class CorrBlock1DHip:
         self._lay_ref = ctypes.byref(self.layout)
         self._out_shape = (self.B, self.num_levels * (2 * self.radius + 1), self.H, self.W1)
 
-    def _lookup(self, coords):
+    def _lookup(self, coords, fp32=False):
+        """fp32=True: the fp32 taps whatever out_dtype says (the fused layer's backward recomputes them)."""
+        vt = self.out_torch_dtype is not torch.float32 and not fp32
         with _on_device(self.device):
-            out = torch.empty(self._out_shape, dtype=torch.float32, device=self.device)
-            rc = lib.rc_lookup_fwd(self._vol_ptr, self._lay_ref, coords.data_ptr(), coords.shape[1],
-                                   out.data_ptr(), self.radius, self.coord_mode, _stream(self.device))
+            out = torch.empty(self._out_shape, dtype=self.out_torch_dtype if vt else torch.float32, device=self.device)
+            fn = lib.rc_lookup_fwd_vt if vt else lib.rc_lookup_fwd
+            rc = fn(self._vol_ptr, self._lay_ref, coords.data_ptr(), coords.shape[1],
+                    out.data_ptr(), self.radius, self.coord_mode, _stream(self.device))
             if rc:
-                check(rc, "rc_lookup_fwd")
+                check(rc, "rc_lookup_fwd_vt" if vt else "rc_lookup_fwd")
         return out
 
     def __call__(self, coords):

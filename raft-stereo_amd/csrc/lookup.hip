@@ -33,31 +33,43 @@ struct lk_update {
 //         that L2 as dirty lines and are written back when the kernel ends -- a tail with nothing to overlap
 //         (KITTI, 8 pairs: 11.1 us against 9.0); the kernel that reads the taps next finds them in the
 //         Infinity Cache either way (tools/lab_consumer.py: lookup + cast 20.0 us with both).
-template <int NT, bool NTS>
-__device__ __forceinline__ void store_taps(float* __restrict__ out, int64_t plane0, int64_t HW, int lane,
+template <int NT, bool NTS, typename OT>
+__device__ __forceinline__ void store_taps(OT* __restrict__ out, int64_t plane0, int64_t HW, int lane,
                                            const float (&tap)[NT]) {
 #pragma unroll
   for (int k = 0; k < NT; ++k) {
-    float* base = out + uniform(plane0 + k * HW);  // scalar
+    OT* base = out + uniform(plane0 + k * HW);  // scalar
+    if constexpr (sizeof(OT) == 4) {
 #ifdef RC_LAB_STORE_POLICY
-    asm volatile("global_store_dword %0, %1, %2 " RC_LAB_STORE_POLICY ::"v"(lane * 4), "v"(tap[k]), "s"(base) : "memory");
+      asm volatile("global_store_dword %0, %1, %2 " RC_LAB_STORE_POLICY ::"v"(lane * 4), "v"(tap[k]), "s"(base) : "memory");
 #else
-    // (spelled out so that the plane's base stays in scalar registers: the builtin takes a 64-bit vector address)
-    if constexpr (NTS) asm volatile("global_store_dword %0, %1, %2 nt" ::"v"(lane * 4), "v"(tap[k]), "s"(base) : "memory");
-    else asm volatile("global_store_dword %0, %1, %2 sc1" ::"v"(lane * 4), "v"(tap[k]), "s"(base) : "memory");
+      // (spelled out so that the plane's base stays in scalar registers: the builtin takes a 64-bit vector address)
+      if constexpr (NTS) asm volatile("global_store_dword %0, %1, %2 nt" ::"v"(lane * 4), "v"(tap[k]), "s"(base) : "memory");
+      else asm volatile("global_store_dword %0, %1, %2 sc1" ::"v"(lane * 4), "v"(tap[k]), "s"(base) : "memory");
 #endif
+    } else {
+      // output in the volume's 16-bit type (rc_lookup_fwd_vt): the fp32 tap rounded once, 128 bytes per plane
+      // (the fp32 value pinned in a register first: left alone, the compiler folds the interpolation's last
+      // fma and the conversion into one v_fma_mixlo_f16, which rounds the unrounded sum -- ties then fall
+      // differently from rc_lookup_fwd's taps converted afterwards)
+      float t32 = tap[k];
+      asm volatile("" : "+v"(t32));
+      const uint32_t bits = (uint32_t)__builtin_bit_cast(uint16_t, rc_from_float<OT>(t32));
+      if constexpr (NTS) asm volatile("global_store_short %0, %1, %2 nt" ::"v"(lane * 2), "v"(bits), "s"(base) : "memory");
+      else asm volatile("global_store_short %0, %1, %2 sc1" ::"v"(lane * 2), "v"(bits), "s"(base) : "memory");
+    }
   }
 }
 
 // A forward pyramid keeps its even levels; levels (i, i+1) are served by one run of level i (pair_fetch in
 // window.h).  ALL4 (the model's configuration, 4 levels): the 16-byte loads of both runs are issued back to
 // back, then decoded, interpolated and stored.  Otherwise one pair (or the odd last level) at a time.
-template <typename VT, int R, int MODE, bool ALL4, bool NTS>
+template <typename VT, int R, int MODE, bool ALL4, bool NTS, typename OT>
 __global__ __launch_bounds__(LK_THREADS) void lookup_fwd_kernel(const VT* __restrict__ vol,
                                                                 rc_dev_layout lay,
                                                                 const float* __restrict__ coords,
                                                                 int coords_channels,
-                                                                float* __restrict__ out,
+                                                                OT* __restrict__ out,
                                                                 int chunks_per_image, int n_items, lk_update upd) {
   using PF = pair_fetch<VT, R, MODE>;
   using SF = single_fetch<VT, R, MODE>;
@@ -91,9 +103,9 @@ __global__ __launch_bounds__(LK_THREADS) void lookup_fwd_kernel(const VT* __rest
   auto emit_pair = [&](PF& pf, int i, const float (&lo)[NW], const float (&hi)[NW]) {
     float tap[NT];
     interp_taps<R, MODE, NW>(lo, pf.s_lo, lay.width[i], pf.x_lo, pf.f_lo, tap);
-    store_taps<NT, NTS>(out, out_u + (int64_t)i * NT * HW, HW, lane, tap);
+    store_taps<NT, NTS, OT>(out, out_u + (int64_t)i * NT * HW, HW, lane, tap);
     interp_taps<R, MODE, NW>(hi, pf.s_hi, lay.width[i + 1], pf.x_hi, pf.f_hi, tap);
-    store_taps<NT, NTS>(out, out_u + (int64_t)(i + 1) * NT * HW, HW, lane, tap);
+    store_taps<NT, NTS, OT>(out, out_u + (int64_t)(i + 1) * NT * HW, HW, lane, tap);
   };
   auto finish_pair = [&](PF& pf, int i) {
     float lo[NW], hi[NW];
@@ -131,7 +143,7 @@ __global__ __launch_bounds__(LK_THREADS) void lookup_fwd_kernel(const VT* __rest
       float v[NW], tap[NT];
       sf.window(lay, i, v);
       interp_taps<R, MODE, NW>(v, sf.pos.wbase, lay.width[i], sf.xi, sf.frac, tap);
-      store_taps<NT, NTS>(out, out_u + (int64_t)i * NT * HW, HW, lane, tap);
+      store_taps<NT, NTS, OT>(out, out_u + (int64_t)i * NT * HW, HW, lane, tap);
     }
   }
 }
@@ -535,17 +547,17 @@ int dispatch_adjoint_dense(const adj_lists& lists, const adj_dims& d, void* dC, 
 // (lookup + cast: 20.0 -> 20.9 us): those use agent-scope stores instead (store_taps).
 constexpr int64_t LK_NT_STORE_BYTES = 160ll << 20;
 
-template <typename VT, int R, int MODE>
-int launch_fwd_mode(const void* vol, rc_dev_layout d, const float* coords, int cc, float* out, hipStream_t st,
+template <typename VT, int R, int MODE, typename OT>
+int launch_fwd_mode(const void* vol, rc_dev_layout d, const float* coords, int cc, OT* out, hipStream_t st,
                     const lk_update& upd) {
   using PI = pair_info<vt_info<VT>::RB, R, MODE>;
   set_row_bias(d, vt_info<VT>::RB, PI::NW2);
   const int chunks = (d.H * d.W1 + 63) / 64;
   const int n_items = (int)((int64_t)d.B * chunks);
   const int blocks = (n_items + (LK_THREADS / 64) - 1) / (LK_THREADS / 64);
-  const bool nts = (int64_t)d.B * d.L * (2 * R + 1) * d.H * d.W1 * 4 > LK_NT_STORE_BYTES;
+  const bool nts = (int64_t)d.B * d.L * (2 * R + 1) * d.H * d.W1 * (int64_t)sizeof(OT) > LK_NT_STORE_BYTES;
 #define RC_LK(ALL4, NTS)                                                                                       \
-  hipLaunchKernelGGL((lookup_fwd_kernel<VT, R, MODE, ALL4, NTS>), dim3(blocks), dim3(LK_THREADS), 0, st,      \
+  hipLaunchKernelGGL((lookup_fwd_kernel<VT, R, MODE, ALL4, NTS, OT>), dim3(blocks), dim3(LK_THREADS), 0, st,  \
                      (const VT*)vol, d, coords, cc, out, chunks, n_items, upd)
   if (R == 4 && d.L == 4) {  // the model's configuration: all levels' loads in flight together
     if (nts) RC_LK((R == 4), true);
@@ -558,25 +570,25 @@ int launch_fwd_mode(const void* vol, rc_dev_layout d, const float* coords, int c
   return rc_check_launch("rc_lookup_fwd");
 }
 
-template <typename VT, int R>
-int launch_fwd(const void* vol, const rc_dev_layout& d, const float* coords, int cc, float* out, int mode,
+template <typename VT, int R, typename OT>
+int launch_fwd(const void* vol, const rc_dev_layout& d, const float* coords, int cc, OT* out, int mode,
                hipStream_t st, const lk_update& upd) {
-  return mode == RC_COORD_EXACT ? launch_fwd_mode<VT, R, RC_COORD_EXACT>(vol, d, coords, cc, out, st, upd)
-                                : launch_fwd_mode<VT, R, RC_COORD_GRIDSAMPLE>(vol, d, coords, cc, out, st, upd);
+  return mode == RC_COORD_EXACT ? launch_fwd_mode<VT, R, RC_COORD_EXACT, OT>(vol, d, coords, cc, out, st, upd)
+                                : launch_fwd_mode<VT, R, RC_COORD_GRIDSAMPLE, OT>(vol, d, coords, cc, out, st, upd);
 }
 
-template <typename VT>
-int dispatch_fwd_radius(const void* vol, const rc_dev_layout& d, const float* coords, int cc, float* out,
+template <typename VT, typename OT>
+int dispatch_fwd_radius(const void* vol, const rc_dev_layout& d, const float* coords, int cc, OT* out,
                         int radius, int mode, hipStream_t st, const lk_update& upd) {
   switch (radius) {
-    case 1: return launch_fwd<VT, 1>(vol, d, coords, cc, out, mode, st, upd);
-    case 2: return launch_fwd<VT, 2>(vol, d, coords, cc, out, mode, st, upd);
-    case 3: return launch_fwd<VT, 3>(vol, d, coords, cc, out, mode, st, upd);
-    case 4: return launch_fwd<VT, 4>(vol, d, coords, cc, out, mode, st, upd);
-    case 5: return launch_fwd<VT, 5>(vol, d, coords, cc, out, mode, st, upd);
-    case 6: return launch_fwd<VT, 6>(vol, d, coords, cc, out, mode, st, upd);
-    case 7: return launch_fwd<VT, 7>(vol, d, coords, cc, out, mode, st, upd);
-    case 8: return launch_fwd<VT, 8>(vol, d, coords, cc, out, mode, st, upd);
+    case 1: return launch_fwd<VT, 1, OT>(vol, d, coords, cc, out, mode, st, upd);
+    case 2: return launch_fwd<VT, 2, OT>(vol, d, coords, cc, out, mode, st, upd);
+    case 3: return launch_fwd<VT, 3, OT>(vol, d, coords, cc, out, mode, st, upd);
+    case 4: return launch_fwd<VT, 4, OT>(vol, d, coords, cc, out, mode, st, upd);
+    case 5: return launch_fwd<VT, 5, OT>(vol, d, coords, cc, out, mode, st, upd);
+    case 6: return launch_fwd<VT, 6, OT>(vol, d, coords, cc, out, mode, st, upd);
+    case 7: return launch_fwd<VT, 7, OT>(vol, d, coords, cc, out, mode, st, upd);
+    case 8: return launch_fwd<VT, 8, OT>(vol, d, coords, cc, out, mode, st, upd);
   }
   rc_set_error("radius %d outside 1..%d", radius, RC_MAX_RADIUS);
   return RC_EUNSUPPORTED;
@@ -603,8 +615,9 @@ int launch_bwd(const float* coords, int cc, const float* gout, float* gvol, cons
 
 }  // namespace
 
+// out_vt: the output is in the volume's own type (rc_lookup_fwd_vt) instead of fp32
 static int lookup_fwd_any(const void* vol, const rc_layout* lay, const float* coords, int coords_channels,
-                          float* out, int radius, int coord_mode, void* stream, const lk_update& upd) {
+                          void* out, bool out_vt, int radius, int coord_mode, void* stream, const lk_update& upd) {
   int rc = check_common(lay, vol, coords, out, coords_channels, radius, coord_mode);
   if (rc) return rc;
   RC_REQUIRE(!lay->full, RC_EINVAL, "rc_lookup_fwd takes a forward pyramid (rc_pyramid_layout)");
@@ -612,11 +625,15 @@ static int lookup_fwd_any(const void* vol, const rc_layout* lay, const float* co
   hipStream_t st = (hipStream_t)stream;
   switch (lay->dtype) {
     case RC_F32:
-      return dispatch_fwd_radius<float>(vol, d, coords, coords_channels, out, radius, coord_mode, st, upd);
+      return dispatch_fwd_radius<float, float>(vol, d, coords, coords_channels, (float*)out, radius, coord_mode, st, upd);
     case RC_F16:
-      return dispatch_fwd_radius<rc_half>(vol, d, coords, coords_channels, out, radius, coord_mode, st, upd);
+      if (out_vt)
+        return dispatch_fwd_radius<rc_half, rc_half>(vol, d, coords, coords_channels, (rc_half*)out, radius, coord_mode, st, upd);
+      return dispatch_fwd_radius<rc_half, float>(vol, d, coords, coords_channels, (float*)out, radius, coord_mode, st, upd);
     case RC_BF16:
-      return dispatch_fwd_radius<rc_bf16>(vol, d, coords, coords_channels, out, radius, coord_mode, st, upd);
+      if (out_vt)
+        return dispatch_fwd_radius<rc_bf16, rc_bf16>(vol, d, coords, coords_channels, (rc_bf16*)out, radius, coord_mode, st, upd);
+      return dispatch_fwd_radius<rc_bf16, float>(vol, d, coords, coords_channels, (float*)out, radius, coord_mode, st, upd);
   }
   rc_set_error("unknown pyramid dtype %d", lay->dtype);
   return RC_EUNSUPPORTED;
@@ -624,7 +641,12 @@ static int lookup_fwd_any(const void* vol, const rc_layout* lay, const float* co
 
 extern "C" int rc_lookup_fwd(const void* vol, const rc_layout* lay, const float* coords, int coords_channels,
                              float* out, int radius, int coord_mode, void* stream) {
-  return lookup_fwd_any(vol, lay, coords, coords_channels, out, radius, coord_mode, stream, lk_update{});
+  return lookup_fwd_any(vol, lay, coords, coords_channels, out, false, radius, coord_mode, stream, lk_update{});
+}
+
+extern "C" int rc_lookup_fwd_vt(const void* vol, const rc_layout* lay, const float* coords, int coords_channels,
+                                void* out, int radius, int coord_mode, void* stream) {
+  return lookup_fwd_any(vol, lay, coords, coords_channels, out, true, radius, coord_mode, stream, lk_update{});
 }
 
 extern "C" int rc_lookup_fwd_update(const void* vol, const rc_layout* lay, const float* coords,
@@ -632,7 +654,7 @@ extern "C" int rc_lookup_fwd_update(const void* vol, const rc_layout* lay, const
                                     float* flow_out, float* out, int radius, int coord_mode, void* stream) {
   RC_REQUIRE(delta_flow && coords_out && flow_out, RC_EINVAL, "null pointer argument");
   const lk_update upd = {delta_flow, coords_out, flow_out};
-  return lookup_fwd_any(vol, lay, coords, coords_channels, out, radius, coord_mode, stream, upd);
+  return lookup_fwd_any(vol, lay, coords, coords_channels, out, false, radius, coord_mode, stream, upd);
 }
 
 extern "C" int rc_lookup_bwd(const float* coords, int coords_channels, const float* grad_out,

@@ -179,6 +179,9 @@ __device__ __forceinline__ void decode_pair(uint32_t (&d)[ND], int o, int bit, f
 // already zero outside the image): floor + lerp (sampler_kernel.cu:42-57) or the reference's grid_sample
 // coordinate round trip (core/corr.py:137, core/utils/utils.py:63), whose fp32 rounding can move a tap across
 // an integer -- the window is one entry wider on both sides for that.
+// Every tap is product + fma in a FIXED order (spelled out: of `a*b + c*d` the compiler contracts whichever
+// product it likes, differently from one instantiation to the next, and rc_lookup_fwd_vt's taps must be
+// rc_lookup_fwd's rounded).
 template <int R, int MODE, int NW>
 __device__ __forceinline__ void interp_taps(const float (&v)[NW], int wbase, int Wi, float xi, float frac,
                                             float (&tap)[2 * R + 1]) {
@@ -186,7 +189,7 @@ __device__ __forceinline__ void interp_taps(const float (&v)[NW], int wbase, int
   if constexpr (MODE == RC_COORD_EXACT) {
     const float a = frac, bw = 1.0f - a;
 #pragma unroll
-    for (int k = 0; k < NT; ++k) tap[k] = v[k] * bw + v[k + 1] * a;
+    for (int k = 0; k < NT; ++k) tap[k] = __builtin_fmaf(v[k + 1], a, v[k] * bw);
   } else {
     const float wm1 = (float)(Wi - 1);
     int dlt[NT];  // where grid_sample's floor landed relative to tap k: -1, 0 or +1
@@ -210,11 +213,11 @@ __device__ __forceinline__ void interp_taps(const float (&v)[NW], int wbase, int
         const bool lt = dlt[k] < 0, gt = dlt[k] > 0;
         const float va = lt ? a0 : (gt ? a2 : a1);
         const float vb = lt ? a1 : (gt ? a3 : a2);
-        tap[k] = va * w0[k] + vb * w1w[k];
+        tap[k] = __builtin_fmaf(vb, w1w[k], va * w0[k]);
       }
     } else {
 #pragma unroll
-      for (int k = 0; k < NT; ++k) tap[k] = v[k + EXT] * w0[k] + v[k + EXT + 1] * w1w[k];
+      for (int k = 0; k < NT; ++k) tap[k] = __builtin_fmaf(v[k + EXT + 1], w1w[k], v[k + EXT] * w0[k]);
     }
   }
 }

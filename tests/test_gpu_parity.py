@@ -240,6 +240,67 @@ def test_16bit_backward(R, golden, dtype):
     assert rel(f1.grad, rd1) < TOL16[dtype] and rel(f2.grad, rd2) < TOL16[dtype]
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("mode", ["exact", "gridsample"])
+@pytest.mark.parametrize("shape,L,r", [((2, 64, 3, 45, 45), 4, 4), ((1, 32, 2, 131, 70), 3, 2), ((1, 32, 5, 64, 257), 2, 7),
+                                       ((8, 256, 96, 312, 312), 4, 4)])
+def test_lookup_in_the_volumes_type_is_the_fp32_lookup_rounded_once(R, dtype, mode, shape, L, r):
+    """rc_lookup_fwd_vt (what CorrBlockFast1D returns under mixed precision: the sampler's output has the volume's
+    options, core/corr.py:44-51, sampler_kernel.cu:122-124): bit-equal to rc_lookup_fwd's fp32 taps rounded to
+    nearest even, at ragged sizes and at the KITTI size; the gradient path takes the 16-bit gradients it gets."""
+    B, D, H, W1, W2 = shape
+    g = torch.Generator(device="cuda").manual_seed(B * 1000 + W1)
+    f1 = torch.randn((B, D, H, W1), generator=g, device="cuda").to(dtype)
+    f2 = torch.randn((B, D, H, W2), generator=g, device="cuda").to(dtype)
+    coords = dev(O.synthetic_coords(B, H, W1, seed=5))
+    coords[:, 0] = coords[:, 0] * (W2 / W1) + torch.rand(coords[:, 0].shape, generator=g, device="cuda") * 9 - 4
+    coords[0, 0, 0, :8] = torch.tensor([-40., -1.5, -0.25, 0., W2 - 1.0, W2 - 0.5, W2 + 3.25, 1e6], device="cuda")[:min(8, W1)]
+    ref = R.CorrBlock1DHip(f1, f2, num_levels=L, radius=r, coord_mode=mode)
+    blk = R.CorrBlock1DHip(f1, f2, num_levels=L, radius=r, coord_mode=mode, out_dtype=dtype)
+    out, out32 = blk(coords), ref(coords)
+    assert out.dtype == dtype and out32.dtype == torch.float32 and out.shape == out32.shape
+    assert torch.equal(out, out32.to(dtype))
+    assert out32.abs().max() > 0
+    with pytest.raises(TypeError):
+        R.CorrBlock1DHip(f1, f2, num_levels=L, radius=r, out_dtype=torch.float64)
+    if B * H * W1 > 10000:
+        return
+    # gradients: the same feature gradients as the fp32-output block given the same (16-bit representable) gradient
+    gout = torch.randn(out.shape, generator=g, device="cuda").to(dtype)
+    grads = []
+    for od in (dtype, None):
+        a, b = f1.clone().requires_grad_(True), f2.clone().requires_grad_(True)
+        o = R.CorrBlock1DHip(a, b, num_levels=L, radius=r, coord_mode=mode, out_dtype=od)(coords)
+        (o * gout.to(o.dtype)).sum().backward()
+        grads.append((a.grad, b.grad))
+    assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
+
+
+def test_lookup_in_the_volumes_type_raw_abi_and_streamed_stores(R):
+    """Through the C ABI: an fp32 pyramid's rc_lookup_fwd_vt is rc_lookup_fwd; an output beyond the
+    non-temporal threshold (160 MB: 80 KITTI pairs of 16-bit taps) equals the fp32 one rounded."""
+    from raft_stereo_amd._lib import lib
+    g = torch.Generator(device="cuda").manual_seed(3)
+    f1 = torch.randn((1, 64, 3, 50), generator=g, device="cuda")
+    f2 = torch.randn((1, 64, 3, 50), generator=g, device="cuda")
+    blk = R.CorrBlock1DHip(f1, f2, num_levels=4, radius=4)
+    coords = dev(O.synthetic_coords(1, 3, 50, seed=2))
+    a, b = torch.empty(blk._out_shape, device="cuda"), torch.empty(blk._out_shape, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    for fn, o in ((lib.rc_lookup_fwd, a), (lib.rc_lookup_fwd_vt, b)):
+        assert fn(blk._vol_ptr, blk._lay_ref, coords.data_ptr(), 2, o.data_ptr(), 4, blk.coord_mode, st) == 0
+    assert torch.equal(a, b) and a.abs().max() > 0
+    assert lib.rc_lookup_fwd_vt(blk._vol_ptr, blk._lay_ref, coords.data_ptr(), 2, None, 4, blk.coord_mode, st) != 0
+    B, D, H, W = 80, 32, 96, 312
+    h1 = torch.randn((B, D, H, W), generator=g, device="cuda").half()
+    h2 = torch.randn((B, D, H, W), generator=g, device="cuda").half()
+    c = dev(O.synthetic_coords(B, H, W, seed=4))
+    o16 = R.CorrBlock1DHip(h1, h2, out_dtype=torch.float16)(c)
+    assert o16.numel() * 2 > 160 << 20
+    o32 = R.CorrBlock1DHip(h1, h2)(c)
+    assert torch.equal(o16, o32.half())
+
+
 # ------------------------------------------------------------------ corr_sampler twin
 @pytest.mark.parametrize("case", ["tiny_b2_d32_h3_w24", "odd_b1_d64_h2_w40x45"])
 @pytest.mark.parametrize("kind", KINDS)
