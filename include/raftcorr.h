@@ -22,6 +22,8 @@
  *   rc_lookup_fwd      core/corr.py:127-146 (reg, grid_sample coordinates) and
  *                      core/corr.py:44-51 -> sampler/sampler.cpp:24-32 ->
  *                      sampler/sampler_kernel.cu:19-60,107-136 (reg_cuda), all levels at once
+ *   rc_lookup_fwd_vt   the same with the taps in the volume's type: what core/corr.py:44-51 returns under
+ *                      mixed precision (sampler/sampler_kernel.cu:122-124 allocates volume.options())
  *   rc_lookup_bwd      core/corr.py:24-29 -> sampler/sampler.cpp:34-45 ->
  *                      sampler/sampler_kernel.cu:63-105,138-166
  *   rc_build_bwd       autograd of core/corr.py:119-125 (avg_pool2d chain) and :154-156
