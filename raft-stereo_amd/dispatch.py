@@ -25,15 +25,21 @@ def wants_autocast(corr_implementation):
     return corr_implementation.endswith("_cuda") or corr_implementation.endswith("_hip")
 
 
-def make_corr_fn(corr_implementation, fmap1, fmap2, radius=4, num_levels=4, mixed_precision=False):
+def make_corr_fn(corr_implementation, fmap1, fmap2, radius=4, num_levels=4, mixed_precision=False, out_dtype=None):
     """What core/raft_stereo.py:90-100 does for the names this package owns.  Unknown names
-    raise (the reference falls through its if/elif and dies with UnboundLocalError)."""
+    raise (the reference falls through its if/elif and dies with UnboundLocalError).
+    out_dtype (reg_hip with 16-bit feature maps only): the taps in the volume's dtype, as the reference's
+    reg_cuda block returns them (core/corr.py:44-51), instead of fp32."""
     if corr_implementation not in CORR_IMPLEMENTATIONS:
         raise ValueError(f"corr_implementation {corr_implementation!r} is not provided by raft_stereo_amd; "
                          f"choices: {sorted(CORR_IMPLEMENTATIONS)}")
     cls, to_fp32 = CORR_IMPLEMENTATIONS[corr_implementation]
     if to_fp32 and not mixed_precision:
         fmap1, fmap2 = fmap1.float(), fmap2.float()
+    if out_dtype is not None:
+        if cls is not CorrBlock1DHip:
+            raise ValueError(f"out_dtype is a reg_hip option, not one of {corr_implementation!r}")
+        return cls(fmap1, fmap2, radius=radius, num_levels=num_levels, out_dtype=out_dtype)
     return cls(fmap1, fmap2, radius=radius, num_levels=num_levels)
 
 

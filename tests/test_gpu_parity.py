@@ -955,6 +955,13 @@ def test_argument_errors(R):
         R.make_corr_fn("reg_cuda", f, f)
     out = R.make_corr_fn("reg_hip", f.half(), f.half(), radius=4, num_levels=4)(torch.zeros(1, 2, 2, 32, device="cuda"))
     assert out.shape == (1, 36, 2, 32)
+    out = R.make_corr_fn("reg_hip", f.half(), f.half(), radius=4, num_levels=4, mixed_precision=True,
+                         out_dtype=torch.float16)(torch.zeros(1, 2, 2, 32, device="cuda"))
+    assert out.shape == (1, 36, 2, 32) and out.dtype == torch.float16
+    with pytest.raises(ValueError):
+        R.make_corr_fn("alt_hip", f.half(), f.half(), mixed_precision=True, out_dtype=torch.float16)
+    with pytest.raises(TypeError):             # fp32 feature maps (no mixed precision) have an fp32 pyramid
+        R.make_corr_fn("reg_hip", f, f, out_dtype=torch.float16)
     # non-contiguous views (shared-backbone split, core/raft_stereo.py:80) are accepted
     both = torch.randn(2, 32, 2, 32, device="cuda")
     a, b = both.split(1, dim=0)
