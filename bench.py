@@ -901,13 +901,13 @@ def main():
     elif args.loop_only:
         if rank == 0 and not cfg["train"]:
             extra.update(refine_loop(step, cfg, device, capture=False, baseline=False))
-    elif not is_alt and not cfg["train"] and rank == 0:
+    elif not is_alt and not cfg["train"] and world == 1:       # side legs: single-GPU runs only (with more ranks
         extra.update(fused_convc1(step, cfg, device))      # after the timed region: not part of `value`
         if cfg["H"] * cfg["W"] * cfg["W"] * cfg["batch"] <= (1 << 28):
             extra.update(sampler_twin(cfg, device))
-    if not args.loop_only and rank == 0 and cfg["H"] * cfg["W"] * cfg["batch"] <= 300000:
+    if not args.loop_only and world == 1 and cfg["H"] * cfg["W"] * cfg["batch"] <= 300000:   # the others would idle in a barrier)
         extra.update(update_ops(cfg, device))              # side metrics, after the timed region
-    if (not args.loop_only and not cfg["train"] and rank == 0 and cfg["H"] * cfg["W"] * cfg["batch"] <= 300000
+    if (not args.loop_only and not cfg["train"] and world == 1 and cfg["H"] * cfg["W"] * cfg["batch"] <= 300000
             and not args.no_refine_loop):
         extra.update(refine_loop(step, cfg, device, capture=world == 1 and not profiler))
     if cfg["train"] and not args.no_refine_loop and not args.loop_only and (rank == 0 or world > 1):
@@ -920,7 +920,7 @@ def main():
         extra.update(hip_graph_step(cfg, device, 1234 + rank))
     if profiler:
         extra["profiler_attached"] = True
-    if (args.workload == "kitti" and not args.batch and not args.dtype and rank == 0 and not args.loop_only
+    if (args.workload == "kitti" and not args.batch and not args.dtype and world == 1 and not args.loop_only
             and not args.profile):
         # the same kernel with nothing left in the Infinity Cache between lookups (after the timed region)
         extra["roofline_hbm_resident"] = hbm_resident_lookup(cfg, device, 1234 + rank)
