@@ -324,10 +324,13 @@ class CorrBlock1DHip:
 
     def _lookup_convc1(self, coords, weight, bias, relu):
         K = self.num_levels * (2 * self.radius + 1)
-        key = (weight.data_ptr(), weight._version, bias.data_ptr(), bias._version)
+        try:
+            key = (weight.data_ptr(), weight._version, bias.data_ptr(), bias._version)
+        except RuntimeError:      # inference-mode tensors have no version counter: re-pack on every call
+            key = None
         with torch.cuda.device(self.device):
             st = _stream(self.device)
-            if getattr(self, "_convc1_key", None) != key:
+            if key is None or getattr(self, "_convc1_key", None) != key:
                 w32 = weight.detach().reshape(_lib.RC_CONVC1_OUT, K).float().contiguous()
                 self._convc1_packed = torch.empty(_lib.RC_CONVC1_OUT * 64, dtype=self.volume_torch_dtype,
                                                   device=self.device)

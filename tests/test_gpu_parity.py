@@ -749,6 +749,14 @@ def test_lookup_convc1_rejects_bad_weights(R):
     c = torch.zeros(1, 2, 2, 32, device="cuda")
     with pytest.raises(ValueError):
         blk.lookup_convc1(c, torch.zeros(64, 35, device="cuda"), torch.zeros(64, device="cuda"))
+    # parameters made under torch.inference_mode() have no version counter: accepted, same result
+    g = torch.Generator(device="cuda").manual_seed(1)
+    w, b = torch.randn(64, 36, generator=g, device="cuda"), torch.randn(64, generator=g, device="cuda")
+    ref = blk.lookup_convc1(c, w, b)
+    with torch.inference_mode():
+        wi, bi = w.clone(), b.clone()
+        out = blk.lookup_convc1(c, wi, bi)
+    assert torch.equal(out, ref)
 
 
 @pytest.mark.parametrize("case", CONVC1_CASES)
