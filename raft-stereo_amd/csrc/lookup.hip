@@ -545,7 +545,10 @@ int dispatch_adjoint_dense(const adj_lists& lists, const adj_dims& d, void* dC, 
 // are written with non-temporal stores (KITTI, 64 pairs: 104 -> 94 us).  Non-temporal stores make the kernel
 // faster on smaller outputs too (8 pairs: 11.1 -> 9.7 us) but the consumer then pays more than that
 // (lookup + cast: 20.0 -> 20.9 us): those use agent-scope stores instead (store_taps).
-constexpr int64_t LK_NT_STORE_BYTES = 160ll << 20;
+#ifndef RC_LAB_LK_NT_BYTES  // lab builds move the threshold (0: always non-temporal; huge: never)
+#define RC_LAB_LK_NT_BYTES (160ll << 20)
+#endif
+constexpr int64_t LK_NT_STORE_BYTES = RC_LAB_LK_NT_BYTES;
 
 template <typename VT, int R, int MODE, typename OT>
 int launch_fwd_mode(const void* vol, rc_dev_layout d, const float* coords, int cc, OT* out, hipStream_t st,
