@@ -596,11 +596,9 @@ def refine_train_step(step, cfg, device, reps=2, dist=None):
     model = Refiner(blk)
     if world > 1:
         from torch.nn.parallel import DistributedDataParallel
-        # the default 25 MB buckets, all-reduced while the backward pass is still running.  (The rehearsal of
-        # this leg with two ranks on ONE GPU over gloo stalls in a backward pass, sooner or later, whatever the
-        # bucket options -- and so does plain torch DDP without a kernel of this library, on the second step:
-        # tools/lab_ddp_gloo_control.py.  CPU tensors over gloo are fine (tests/test_cpu_host.py); RCCL needs
-        # more than one GPU, which the boxes this was built on do not have.)
+        # the default 25 MB buckets, all-reduced while the backward pass is still running.  (main() refuses this
+        # leg when several ranks share one device: tools/lab_ddp_gloo_control.py.  CPU tensors over gloo are
+        # covered by tests/test_cpu_host.py; RCCL needs more than one GPU.)
         model = DistributedDataParallel(model, device_ids=[device.index], gradient_as_bucket_view=False)
         note("update block wrapped in DistributedDataParallel")
         if os.environ.get("RC_BENCH_VERBOSE"):
@@ -811,7 +809,15 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    local_rank = local_rank % max(torch.cuda.device_count(), 1)     # (a rehearsal may put several ranks on one GPU)
+    if world > max(torch.cuda.device_count(), 1) and WORKLOADS[args.workload]["train"] and not args.no_refine_loop \
+            and not args.profile and not args.loop_only:
+        # several ranks on one device + DistributedDataParallel: torch's DDP over gloo stalls in a backward pass in
+        # that arrangement, with or without a kernel of this library (profiles/r02/lab_ddp_gloo_control_one_gpu.txt)
+        raise SystemExit(f"refusing the DDP training leg with {world} ranks on {torch.cuda.device_count()} GPU(s): "
+                         "DistributedDataParallel with several ranks sharing one device stalls in backward "
+                         "(profiles/r02/lab_ddp_gloo_control_one_gpu.txt); use one GPU per rank, or --no-refine-loop "
+                         "for the forward/backward correlation step alone")
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)     # (an inference rehearsal may put several ranks on one GPU)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None

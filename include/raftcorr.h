@@ -54,7 +54,7 @@ extern "C" {
 #define RC_MAX_FUSED_LOOKUPS 32  /* lookups one rc_lookup_bwd_dense call can take */
 #define RC_CONVC1_OUT 64         /* output channels of the motion encoder's convc1 (core/update.py:71) */
 #define RC_CONVC1_MAX_RADIUS 7   /* rc_lookup_convc1_fwd: a level's 2r+1 taps must fit 16 MFMA K slots */
-#define RC_SAMPLER_MAX_RADIUS 7  /* rc_sampler_fwd/bwd: a pixel's 2r+2 taps are served by a quarter wave (16 lanes) */
+#define RC_SAMPLER_MAX_RADIUS 7  /* rc_sampler_fwd/bwd: one kernel instantiation per radius (forward: 2r+2 volume entries per lane in registers) */
 #define RC_ALT_MAX_RADIUS 6      /* rc_alt_fwd: the union of 16 pixels' tap windows must fit the wave's MFMA tiles */
 
 /* element types of feature maps / volumes */

@@ -13,6 +13,7 @@ Torch only owns memory, streams and the autograd graph here; all arithmetic is i
 library.  There is no CPU or eager fallback: tensors must live on a GPU.
 """
 import ctypes
+import weakref
 
 import torch
 
@@ -94,7 +95,10 @@ class _BuildFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, fmap1, fmap2, block):
         block._build(fmap1, fmap2)
-        ctx.block = block
+        # a weak reference: block -> token -> this node -> ctx -> block would be a cycle, and the pyramid would then
+        # wait for Python's cyclic collector instead of being freed with the block.  Every lookup node holds the
+        # block strongly (it needs the pyramid), so the block is alive here whenever a lookup took part in the loss.
+        ctx.block = weakref.ref(block)
         ctx.save_for_backward(fmap1, fmap2)
         ctx.set_materialize_grads(False)    # the token's gradient carries nothing: lookups return None for it
         return torch.zeros(1, dtype=torch.float32, device=fmap1.device)
@@ -102,8 +106,10 @@ class _BuildFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, _grad_token):
         fmap1, fmap2 = ctx.saved_tensors
-        block = ctx.block
-        pending, block._pending = block._pending, []
+        block = ctx.block()
+        pending = []
+        if block is not None:
+            pending, block._pending = block._pending, []
         if not pending:           # no lookup took part in the loss
             return torch.zeros_like(fmap1), torch.zeros_like(fmap2), None
         df1, df2 = torch.empty_like(fmap1), torch.empty_like(fmap2)

@@ -69,6 +69,8 @@ def global_batch_loss(loss_local, count_local, group=None):
                              gradient is exactly the gradient of the global-batch loss)
         loss_global        = sum over ranks of loss_local * count_local / count_global   (detached; for logging)
 
+    A rank without a single valid pixel (its local mean is over nothing: NaN) contributes zero -- its loss is
+    replaced by 0 * nan_to_num(loss), which keeps its autograd graph so that DDP still sees every parameter.
     With one rank (or torch.distributed not initialised) it returns the loss unchanged."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
@@ -77,6 +79,8 @@ def global_batch_loss(loss_local, count_local, group=None):
     cnt = torch.tensor([float(count_local)], dtype=torch.float64, device=loss_local.device)
     dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
     share = float(count_local) / max(float(cnt.item()), 1.0)
+    if count_local == 0:
+        loss_local = torch.nan_to_num(loss_local, nan=0.0, posinf=0.0, neginf=0.0) * 0.0
     num = (loss_local.detach().double() * share).reshape(1).clone()
     dist.all_reduce(num, op=dist.ReduceOp.SUM, group=group)
     return loss_local * (share * world), num[0].to(loss_local.dtype)

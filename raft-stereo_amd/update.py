@@ -211,7 +211,9 @@ class ConvGRUHip(nn.Module):
                 w = torch.cat([self.convz.weight, self.convr.weight], dim=0).to(dt)
                 b = torch.cat([self.convz.bias, self.convr.bias], dim=0).to(dt)
                 old = getattr(self, "_zr_w", None)
-                if old is not None and old.shape == w.shape and old.dtype == w.dtype and old.device == w.device:
+                # (an in-place update of a tensor made under inference_mode is only legal under inference_mode)
+                if old is not None and old.shape == w.shape and old.dtype == w.dtype and old.device == w.device \
+                        and not (old.is_inference() and not torch.is_inference_mode_enabled()):
                     self._zr_w.copy_(w)
                     self._zr_b.copy_(b)
                 else:

@@ -182,26 +182,31 @@ def loss_of(model, xs, gts, valids):
         tot = tot + gamma ** (n_pred - i - 1) * (preds[:, i:i + 1] - gts).abs()[mask].mean()
     return tot, int(mask.sum()), [preds[:, i:i + 1] for i in range(n_pred)]
 
-# one rank, the global batch (what nn.DataParallel + the loss on the gathered batch computes, train_stereo.py:186-193)
-ref_loss, _, ref_preds = loss_of(net, x, gt, valid)
-ref_grads = torch.autograd.grad(ref_loss, list(net.parameters()))
-# ... pinned on the numpy oracle of sequence_loss
-o_loss, _, _ = U.sequence_loss([p.detach().numpy() for p in ref_preds], gt.numpy(), valid.numpy())
-assert abs(float(ref_loss) - float(o_loss)) < 1e-5 * abs(float(o_loss))
-
-# two ranks, half a batch each, DDP + the two scalar all-reduces
-lo, hi = R.shard_pairs(N, ws, rank)
 ddp = DDP(net)
-loss, cnt, _ = loss_of(ddp, x[lo:hi], gt[lo:hi], valid[lo:hi])
-loss = loss if cnt else loss * 0 + sum(p.sum() for p in net.parameters()) * 0     # a rank without valid pixels: nan mean
-loss_bwd, loss_global = R.global_batch_loss(torch.nan_to_num(loss), cnt)
-loss_bwd.backward()
-assert abs(float(loss_global) - float(ref_loss)) < 1e-5 * abs(float(ref_loss)), (float(loss_global), float(ref_loss))
-for p, gr in zip(net.parameters(), ref_grads):
-    assert torch.allclose(p.grad, gr, rtol=1e-4, atol=1e-6), float((p.grad - gr).abs().max())
-# per-rank means averaged with equal weight would NOT be the reference's loss
-naive = torch.tensor([float(torch.nan_to_num(loss))]); dist.all_reduce(naive); naive /= ws
-assert abs(float(naive) - float(ref_loss)) > 1e-3
+lo, hi = R.shard_pairs(N, ws, rank)
+for case in ("uneven", "rank 0 has no valid pixel"):
+    if case != "uneven":
+        valid[:N // ws] = 0.0            # rank 0's local mean is over nothing (NaN): global_batch_loss must cope
+    net.zero_grad(set_to_none=True)
+    # one rank, the global batch (what nn.DataParallel + the loss on the gathered batch computes, train_stereo.py:186-193)
+    ref_loss, _, ref_preds = loss_of(net, x, gt, valid)
+    ref_grads = torch.autograd.grad(ref_loss, list(net.parameters()))
+    # ... pinned on the numpy oracle of sequence_loss
+    o_loss, _, _ = U.sequence_loss([p.detach().numpy() for p in ref_preds], gt.numpy(), valid.numpy())
+    assert abs(float(ref_loss) - float(o_loss)) < 1e-5 * abs(float(o_loss))
+
+    # two ranks, half a batch each, DDP + the two scalar all-reduces
+    loss, cnt, _ = loss_of(ddp, x[lo:hi], gt[lo:hi], valid[lo:hi])
+    assert (cnt == 0) == (case != "uneven" and rank == 0)
+    loss_bwd, loss_global = R.global_batch_loss(loss, cnt)
+    loss_bwd.backward()
+    assert abs(float(loss_global) - float(ref_loss)) < 1e-5 * abs(float(ref_loss)), (case, float(loss_global), float(ref_loss))
+    for p, gr in zip(net.parameters(), ref_grads):
+        assert torch.isfinite(p.grad).all(), case
+        assert torch.allclose(p.grad, gr, rtol=1e-4, atol=1e-6), (case, float((p.grad - gr).abs().max()))
+    # per-rank means averaged with equal weight would NOT be the reference's loss
+    naive = torch.tensor([float(torch.nan_to_num(loss.detach()))]); dist.all_reduce(naive); naive /= ws
+    assert abs(float(naive) - float(ref_loss)) > 1e-3
 seen = torch.ones(1); dist.all_reduce(seen)
 assert int(seen.item()) == ws
 dist.barrier()
@@ -268,3 +273,20 @@ def test_no_kernel_went_to_scratch_memory():
                 offenders.append((os.path.basename(path), name, int(m.group(1))))
     assert n_kernels > 300
     assert not offenders, offenders
+
+
+def test_convgru_stacked_cache_survives_inference_mode_then_no_grad():
+    """ConvGRUHip._stacked refreshes its cached stacked weights in place (so that a captured HIP graph keeps
+    reading current values); buffers made under inference_mode cannot be written in place outside it and must be
+    replaced instead."""
+    import torch
+    import raft_stereo_amd as R
+    gru = R.ConvGRUHip(4, 6)
+    with torch.inference_mode():
+        w0, _ = gru._stacked(torch.float32)
+    assert w0.is_inference()
+    with torch.no_grad():
+        gru.convz.weight.add_(1.0)          # bumps the version counter: the cache is stale
+        w1, b1 = gru._stacked(torch.float32)
+    assert torch.equal(w1, torch.cat([gru.convz.weight, gru.convr.weight], dim=0))
+    assert torch.equal(b1, torch.cat([gru.convz.bias, gru.convr.bias], dim=0))
