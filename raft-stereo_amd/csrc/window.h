@@ -223,17 +223,34 @@ __device__ __forceinline__ void interp_taps(const float (&v)[NW], int wbase, int
 }
 
 // Loads of one window / run: NBLK 16-byte blocks of level `lvl_base` (wave-uniform base of the level's slab
-// of this IMAGE), branch-free: lanes whose window ends early re-read their last block.  `h` is the lane's
-// image row: a wave owns 64 consecutive pixels of the flattened image, so it may straddle two rows.
+// of this IMAGE, `slab_bytes` long), branch-free.  They are buffer loads: a block no entry of which is inside the
+// image (the window hangs over the border, ends before block k, or misses the image altogether -- on the bench's
+// disparity field 12 % of the pixels look left of the image) gets the offset `slab_bytes`, which the buffer's
+// range check turns into zeros WITHOUT a memory access.  Plain loads of "some valid block" instead cost 18 % more
+// lines from memory than the pixels needed.  `h` is the lane's image row: a wave owns 64
+// consecutive pixels of the flattened image, so it may straddle two rows.  `ngroups`: blocks per column that
+// hold image entries.
 template <int NBLK>
-__device__ __forceinline__ void load_blocks(uint32_t (&d)[NBLK * 4], const char* lvl_base, const win_pos& pos, int nb,
-                                            uint32_t blk_bytes, int w1, int h) {
-  const bool tiny = nb < NBLK;
+__device__ __forceinline__ void load_blocks(uint32_t (&d)[NBLK * 4], const char* lvl_base, uint32_t slab_bytes,
+                                            const win_pos& pos, int nb, int ngroups, uint32_t blk_bytes, int w1, int h) {
+  typedef uint32_t u4 __attribute__((ext_vector_type(4)));
   const uint32_t row0 = (uint32_t)h * (uint32_t)nb;
+  const __amdgpu_buffer_rsrc_t rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(lvl_base), 0, (int)slab_bytes, 0x00020000);
+  // blocks klo..khi of the window hold image entries (none: khi < klo)
+  const int klo = max(0, -pos.g0);
+  const int khi = pos.any_ok ? min(pos.nbk, ngroups - 1 - pos.g0) : -1;
+  uint32_t sb = pos.sb0;  // < nb
 #pragma unroll
   for (int k = 0; k < NBLK; ++k) {
-    const uint32_t sb = row_step(pos.sb0, (uint32_t)min(k, pos.nbk), (uint32_t)nb, tiny);
-    const uint4 q = *reinterpret_cast<const uint4*>(lvl_base + (__umul24(row0 + sb, blk_bytes) + (uint32_t)w1 * 16u));
+    if (k > 0) {  // next block row of the column, wrapping around (exact for every nb >= 1)
+      sb += 1;
+      sb = sb == (uint32_t)nb ? 0u : sb;
+    }
+    uint32_t a = __umul24(row0 + sb, blk_bytes) + (uint32_t)w1 * 16u;
+    asm volatile("" : "+v"(a));  // computed for every lane: the select below stays a v_cndmask, not a branch
+    const uint32_t off = (k >= klo && k <= khi) ? a : slab_bytes;
+    const u4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
     d[4 * k + 0] = q.x;
     d[4 * k + 1] = q.y;
     d[4 * k + 2] = q.z;
@@ -263,9 +280,10 @@ template <typename VT, int R, int MODE> struct pair_fetch {
     s_lo = rc_safe_int(fl) - R - PI::EXT;
     s_hi = rc_safe_int(fh) - R - PI::EXT;
     pos = locate_window<RB, LG, PI::NW2>(2 * s_hi, w1, i, lay.width[i], nb, lay.bias[i]);
+    const uint32_t slab = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)lay.H * (uint32_t)nb * blk_bytes);
     const char* lvl = reinterpret_cast<const char*>(vol) +
-                      uniform(lay.offset[i] * (int64_t)sizeof(VT) + (int64_t)b * lay.H * nb * blk_bytes);
-    load_blocks<PI::NBLK>(d, lvl, pos, nb, blk_bytes, w1, h);
+                      uniform(lay.offset[i] * (int64_t)sizeof(VT) + (int64_t)b * slab);
+    load_blocks<PI::NBLK>(d, lvl, slab, pos, nb, (lay.width[i] + RB - 1) >> LG, blk_bytes, w1, h);
   }
 
   // window entries of both levels, zero outside the image
@@ -298,9 +316,10 @@ template <typename VT, int R, int MODE> struct single_fetch {
     const float xf = floorf(xi);
     frac = xi - xf;
     pos = locate_window<RB, LG, WI::NW>(rc_safe_int(xf) - R - WI::EXT, w1, i, lay.width[i], nb, lay.bias[i]);
+    const uint32_t slab = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)lay.H * (uint32_t)nb * blk_bytes);
     const char* lvl = reinterpret_cast<const char*>(vol) +
-                      uniform(lay.offset[i] * (int64_t)sizeof(VT) + (int64_t)b * lay.H * nb * blk_bytes);
-    load_blocks<WI::NBLK>(d, lvl, pos, nb, blk_bytes, w1, h);
+                      uniform(lay.offset[i] * (int64_t)sizeof(VT) + (int64_t)b * slab);
+    load_blocks<WI::NBLK>(d, lvl, slab, pos, nb, (lay.width[i] + RB - 1) >> LG, blk_bytes, w1, h);
   }
 
   __device__ __forceinline__ void window(const rc_dev_layout& lay, int i, float (&v)[WI::NW]) {

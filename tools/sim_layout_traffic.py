@@ -49,10 +49,53 @@ def run(c, name, ext):
               f"{sum(sep):6.1f} B/px   merged (0,1) {m01:5.1f} + (2,3) {m23:5.1f} = {m01 + m23:6.1f} B/px")
 
 
+def kernel_lines(x, predicated):
+    """The lookup kernel's own addressing (csrc/window.h: locate_window, load_blocks), exact mode, 16-bit pyramid:
+    distinct 128-byte lines per pixel and lookup for the runs of level pairs (0,1) and (2,3).
+    predicated=False: round 2's loads -- every lane loads 4 blocks of its run, lanes whose run ends early re-read
+    their last block, lanes whose run misses the image load blocks 0.. of their column, groups left or right of the
+    image wrap around to valid rows; predicated=True: round 3's -- blocks without an image entry are not fetched
+    (buffer loads, offset out of range)."""
+    Bx, Hx, Wx = x.shape
+    w1 = np.arange(Wx)
+    out = []
+    for i in (0, 2):
+        Wi = Wx >> i
+        nb = (Wi + 7) // 8 * 8 // 8
+        s_hi = np.floor(x * 0.5 / 2 ** i).astype(int) - R
+        wb_raw = 2 * s_hi
+        any_ok = (wb_raw + 4 * R + 3 >= 0) & (wb_raw < Wi)
+        wb = np.where(any_ok, wb_raw, 0)
+        g0, o = wb >> 3, wb & 7
+        nbk = (o + 4 * R + 3) >> 3
+        tot = 0
+        for b in range(Bx):
+            keys = []
+            for k in range(4):
+                g = g0[b] + (k if predicated else np.minimum(k, nbk[b]))
+                sb = (g - (w1 >> i) // 8 + nb - 4) % nb
+                key = (np.arange(Hx)[:, None] * 64 + sb) * 64 + w1 // 8
+                if predicated:
+                    keys.append(key[any_ok[b] & (k <= nbk[b]) & (g >= 0) & (g * 8 < Wi)])
+                else:
+                    keys.append(key.ravel())
+            tot += len(np.unique(np.concatenate(keys)))
+        out.append(tot * 128 / (Bx * Hx * Wx))
+    return out
+
+
 if __name__ == "__main__":
     ext = 1 if len(sys.argv) > 1 and sys.argv[1] == "gridsample" else 0
     c = synthetic_coords(B, H, W, seed=1234)
     run(c, "bench", ext)
+    if not ext:
+        rng = np.random.default_rng(0)
+        moved = c[:, 0] + rng.uniform(-1, 1, size=c[:, 0].shape).astype(np.float32)     # bench.py moving_coords
+        for pred in (False, True):
+            a, b = kernel_lines(moved, pred)
+            print(f"kernel addressing, {'round 3 (blocks without image entries not fetched)' if pred else 'round 2 (every lane loads 4 blocks)'}: "
+                  f"(0,1) {a:5.1f} + (2,3) {b:5.1f} = {a + b:6.1f} B/px  (+ 4 B coordinate)")
+        print(f"pixels whose level-0 run misses the image: {((2 * (np.floor(moved / 2).astype(int) - R) + 4 * R + 3) < 0).mean():.3f}")
     c0 = c.copy()
     c0[:, 0] = np.arange(W)[None, None, :] - 20.3
     run(c0, "const", ext)
