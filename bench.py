@@ -26,6 +26,7 @@ import torch  # noqa: E402
 
 METRIC = "corr build TFLOP/s + lookup GB/s; stereo pairs/sec at 1/2/4/8 MI355X"
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_COPY_GBS = 6290.0          # the same guide: what a float4 copy kernel measures (79 % of spec)
 MFMA16_PEAK_TF = 2500.0        # dense fp16/bf16
 MFMA32_PEAK_TF = 157.3         # f32-input MFMA
 
@@ -109,32 +110,60 @@ def moving_coords(coords, iters, seed):
 def measured_traffic(workload, batch, kernel):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this workload
     (profiles/<round>/<workload>_b<batch>_pmc.json, written by tools/pmc_summarize.py): 2 x FETCH_SIZE +
-    WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md.  None when no profile of this exact
-    workload is committed."""
+    WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md.  Returns (bytes, source file) of the newest
+    round that has one, (None, None) when no profile of this exact workload is committed.  This is a figure
+    READ BACK from a committed profile of the same command, not a counter collected in this run (counters need
+    rocprofv3 attached: tools/profile_gpu.sh)."""
     import glob
-    best = None
+    best, src = None, None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"{workload}_b{batch}_pmc.json"))):
         try:
             with open(path) as f:
-                best = json.load(f).get(kernel, {}).get("traffic_bytes_corrected", best)
+                v = json.load(f).get(kernel, {}).get("traffic_bytes_corrected")
         except (OSError, ValueError):
-            pass
-    return None if best is None else int(best)
+            v = None
+        if v is not None:
+            best, src = v, os.path.relpath(path, ROOT)
+    return (None, None) if best is None else (int(best), src)
 
 
 def algorithmic_counts(cfg):
-    """Per-step algorithmic work: build FLOPs/bytes, lookup bytes per launch."""
+    """Per-step algorithmic work: build FLOPs/bytes, lookup bytes per launch.
+
+    Bytes are what the SHIPPED data layout has to move: the build reads both feature maps
+    once and writes the stored (even) levels of the pyramid, 1 + 1/4 (+ 1/16 ...) of level 0; the alt lookup
+    reads the fragment-order copy of f1 and the even levels of the pooled f2 copy, s*D*(1 + 1.25) per pixel.
+    SURVEY 8(d) counted a pyramid with every level stored (1.875 x level 0; f2 copies 1.875 x): those older,
+    larger counts are kept as *_survey_count so that a fraction priced on them can still be read."""
     B, H, W = cfg["batch"], cfg["H"], cfg["W"]
     s = 4 if cfg["dtype"] == "f32" else 2
     nt = 2 * RADIUS + 1
     px = B * H * W
+    stored = sum(0.5 ** i for i in range(0, LEVELS, 2))       # even levels: 1.25 for 4 levels
+    every = sum(0.5 ** i for i in range(LEVELS))              # 1.875
     build_flops = 2.0 * B * H * W * W * D
-    build_bytes = B * H * 2 * W * D * s + B * H * W * W * s * sum(0.5 ** i for i in range(LEVELS))
+    build_in = B * H * 2 * W * D * s
+    build_bytes = build_in + B * H * W * W * s * stored
+    build_bytes_survey = build_in + B * H * W * W * s * every
     lookup_bytes = px * (LEVELS * (2 * RADIUS + 2) * s + 4 + LEVELS * nt * 4)      # 228 B (16-bit) / 308 B (f32)
     alt_flops = px * 2.0 * D * LEVELS * (2 * RADIUS + 2)
-    alt_bytes = px * (s * D * (1 + sum(0.5 ** i for i in range(LEVELS))) + LEVELS * nt * 4 + 4)
-    return dict(pixels=px, build_flops=build_flops, build_bytes=build_bytes, lookup_bytes=lookup_bytes,
-                alt_flops=alt_flops, alt_bytes=alt_bytes)
+    alt_bytes = px * (s * D * (1 + stored) + LEVELS * nt * 4 + 4)
+    alt_bytes_survey = px * (s * D * (1 + every) + LEVELS * nt * 4 + 4)
+    return dict(pixels=px, build_flops=build_flops, build_bytes=build_bytes, build_bytes_survey_count=build_bytes_survey,
+                lookup_bytes=lookup_bytes, alt_flops=alt_flops, alt_bytes=alt_bytes,
+                alt_bytes_survey_count=alt_bytes_survey)
+
+
+def roof_entry(kernel, alg_bytes, us, traffic=(None, None), **more):
+    """One `roofline` object: algorithmic bytes per launch / average launch time against the 8 TB/s spec peak,
+    with the same rate against what a copy kernel reaches on this part beside it."""
+    ach = alg_bytes / (us * 1e-6) / 1e9
+    d = dict(bound="hbm", kernel=kernel, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+             frac=round(ach / HBM_PEAK_GBS, 4), frac_of_measured_copy=round(ach / HBM_COPY_GBS, 4),
+             traffic=traffic[0], traffic_source=traffic[1],
+             algorithmic_bytes_per_launch=int(alg_bytes), avg_launch_us=round(us, 2))
+    d.update(more)
+    return d
 
 
 class Step:
@@ -695,10 +724,7 @@ def hbm_resident_lookup(cfg, device, seed, batch=64, passes=3):
         b.synchronize()
     us = a.elapsed_time(b) / (passes * len(st.coords_list)) * 1e3
     alg = algorithmic_counts(big)["lookup_bytes"]
-    ach = alg / (us * 1e-6) / 1e9
-    return dict(batch=batch, bound="hbm", kernel="lookup_fwd_kernel", achieved=round(ach, 1), peak=HBM_PEAK_GBS,
-                unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), avg_launch_us=round(us, 2),
-                algorithmic_bytes_per_launch=int(alg), traffic=measured_traffic("kitti", batch, "lookup_fwd_kernel"))
+    return roof_entry("lookup_fwd_kernel", alg, us, measured_traffic("kitti", batch, "lookup_fwd_kernel"), batch=batch)
 
 
 def hip_graph_step(cfg, device, seed, n=50):
@@ -870,27 +896,32 @@ def main():
     build_ms = float(np.median(step.build_ms))
     lookup_ms = float(np.median(step.lookup_ms)) / cfg["iters"]        # average per launch
     is_alt = cfg["impl"] == "alt_hip"
+    stock = not args.dtype and not args.adversarial     # the committed profiles are of the stock workloads
     if is_alt:
-        ach = cnt["alt_bytes"] / (lookup_ms * 1e-3) / 1e9
-        roof = dict(bound="hbm", kernel="alt_fwd_kernel", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
-                    algorithmic_bytes_per_launch=int(cnt["alt_bytes"]), avg_launch_us=round(lookup_ms * 1e3, 2),
-                    mfma_tflops=round(cnt["alt_flops"] / (lookup_ms * 1e-3) / 1e12, 2))
+        roof = roof_entry("alt_fwd_kernel", cnt["alt_bytes"], lookup_ms * 1e3,
+                          measured_traffic(args.workload, cfg["batch"], "alt_fwd_kernel") if stock else (None, None),
+                          mfma_tflops=round(cnt["alt_flops"] / (lookup_ms * 1e-3) / 1e12, 2),
+                          frac_survey_count=round(cnt["alt_bytes_survey_count"] / (lookup_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
     else:
-        ach = cnt["lookup_bytes"] / (lookup_ms * 1e-3) / 1e9
-        roof = dict(bound="hbm", kernel="lookup_fwd_kernel", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
-                    algorithmic_bytes_per_launch=int(cnt["lookup_bytes"]), avg_launch_us=round(lookup_ms * 1e3, 2))
+        roof = roof_entry("lookup_fwd_kernel", cnt["lookup_bytes"], lookup_ms * 1e3,
+                          measured_traffic(args.workload, cfg["batch"], "lookup_fwd_kernel") if stock else (None, None))
+    ach = roof["achieved"]
     extra = dict(lookup_gbps=round(ach, 1), lookup_us=round(lookup_ms * 1e3, 2))
     if not is_alt:
         peak = MFMA32_PEAK_TF if cfg["dtype"] == "f32" else MFMA16_PEAK_TF
         tf = cnt["build_flops"] / (build_ms * 1e-3) / 1e12
-        ai = cnt["build_flops"] / cnt["build_bytes"]
-        hbm_cap_tf = ai * HBM_PEAK_GBS / 1e3
+        hbm_cap_tf = cnt["build_flops"] / cnt["build_bytes"] * HBM_PEAK_GBS / 1e3
+        hbm_cap_survey = cnt["build_flops"] / cnt["build_bytes_survey_count"] * HBM_PEAK_GBS / 1e3
+        build_gbps = cnt["build_bytes"] / (build_ms * 1e-3) / 1e9
+        build_tr = measured_traffic(args.workload, cfg["batch"], "build16_kernel" if cfg["dtype"] != "f32" else "build_kernel") \
+            if stock else (None, None)
         extra.update(build_tflops=round(tf, 2), build_ms=round(build_ms, 4), build_frac_mfma=round(tf / peak, 4),
-                     build_gbps=round(cnt["build_bytes"] / (build_ms * 1e-3) / 1e9, 1),
+                     build_gbps=round(build_gbps, 1), build_algorithmic_bytes=int(cnt["build_bytes"]),
                      build_frac_of_binding_roof=round(tf / min(peak, hbm_cap_tf), 4),
-                     build_binding_roof="hbm" if hbm_cap_tf < peak else "mfma")
+                     build_frac_of_measured_copy=round(build_gbps / HBM_COPY_GBS, 4),
+                     build_frac_of_binding_roof_survey_count=round(tf / min(peak, hbm_cap_survey), 4),
+                     build_binding_roof="hbm" if hbm_cap_tf < peak else "mfma",
+                     build_traffic=build_tr[0], build_traffic_source=build_tr[1])
     else:
         extra.update(prepare_ms=round(build_ms, 4))
     if cfg["train"]:
@@ -932,8 +963,6 @@ def main():
         extra["roofline_hbm_resident"] = hbm_resident_lookup(cfg, device, 1234 + rank)
         extra["lookup_frac_hbm_resident"] = extra["roofline_hbm_resident"]["frac"]
 
-    if not args.dtype and not args.adversarial:     # the committed profiles are of the stock workloads
-        roof["traffic"] = measured_traffic(args.workload, cfg["batch"], roof["kernel"])
     line = {
         "metric": METRIC, "value": round(value, 3), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",

@@ -33,7 +33,8 @@
  *   rc_alt_fwd         core/corr.py:64-107 PytorchAlternateCorrBlock1D (volume never built)
  * and, on either side of the lookup (SURVEY.md section 8 f):
  *   rc_lookup_convc1_fwd, rc_convc1_bwd     core/update.py:71,78 on core/raft_stereo.py:110
- *   rc_lookup_fwd_update                    core/raft_stereo.py:109-111,120-123
+ *   rc_lookup_fwd_update,
+ *   rc_lookup_convc1_fwd_update             core/raft_stereo.py:109-111,120-123
  *   rc_gru_gate_r, rc_gru_update (+ _bwd)   core/update.py:23-32
  *   rc_pool2x, rc_interp_bilinear           core/update.py:87-95
  *   rc_upsample_flow_fwd/bwd                core/raft_stereo.py:55-67
@@ -225,6 +226,22 @@ int rc_convc1_pack(const float* weight, int num_levels, int radius, int dtype, v
 int rc_lookup_convc1_fwd(const void* vol, const rc_layout* lay, const float* coords,
                          int coords_channels, const void* packed_weight, const float* bias,
                          void* out, int radius, int coord_mode, int relu, void* stream);
+/*
+ * SURVEY.md section 8(f) ranks 1 + 2 in one launch -- a whole GRU iteration's glue in front of the fused
+ * lookup (core/raft_stereo.py:120-123 of the previous iteration, :109-111 of this one, then core/update.py:78):
+ *     coords_out = coords + (delta_flow[:,0], 0)      delta_flow: [B,2,H,W1] of delta_dtype (RC_F32/F16/BF16:
+ *                                                     what the flow head returns, under autocast 16 bits),
+ *                                                     promoted to fp32 as torch's `+` does; NULL: nothing added
+ *     flow_out   = coords_out - coords0               coords0 = pixel grid (x = w1, y = h)
+ *     out        = relu(convc1(lookup(coords_out)))   as rc_lookup_convc1_fwd
+ * coords_out/flow_out: float [B,2,H,W1]; coords_out may alias coords when coords_channels == 2.  Bit-identical
+ * to rc_lookup_fwd_update's coordinates followed by rc_lookup_convc1_fwd.
+ */
+int rc_lookup_convc1_fwd_update(const void* vol, const rc_layout* lay, const float* coords,
+                                int coords_channels, const void* delta_flow, int delta_dtype,
+                                float* coords_out, float* flow_out, const void* packed_weight,
+                                const float* bias, void* out, int radius, int coord_mode, int relu,
+                                void* stream);
 
 /*
  * Adjoint of rc_lookup_convc1_fwd (autograd of core/update.py:78 on core/raft_stereo.py:110), so the fused

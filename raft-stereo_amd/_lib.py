@@ -68,6 +68,7 @@ SIGNATURES = {
     "rc_build_bwd_dense": (_I, [_P, _LP, _P, _P, _P, _P, _L, _I, _P]),
     "rc_convc1_pack": (_I, [_P, _I, _I, _I, _P, _P]),
     "rc_lookup_convc1_fwd": (_I, [_P, _LP, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
+    "rc_lookup_convc1_fwd_update": (_I, [_P, _LP, _P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "rc_convc1_bwd_work_bytes": (_L, []),
     "rc_convc1_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _L, _I, _I, _P]),
     "rc_convc1_bwd_static": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _L, _I, _I, _P]),

@@ -328,22 +328,69 @@ class CorrBlock1DHip:
             return _LookupConvc1Fn.apply(self._token, coords, weight, bias, self, bool(relu))
         return self._lookup_convc1(coords, weight, bias, relu)
 
-    def _lookup_convc1(self, coords, weight, bias, relu):
+    def update_lookup_convc1(self, coords1, delta_flow, weight, bias, relu=True):
+        """A whole GRU iteration's glue and the fused lookup in ONE kernel (inference):
+        `delta_flow[:,1] = 0; coords1 = coords1 + delta_flow` of the previous iteration
+        (core/raft_stereo.py:120-123; `delta_flow=None` on the first iteration: nothing is added), then
+        `flow = coords1 - coords0` (:111) and `relu(convc1(corr_fn(coords1)))` (:110, core/update.py:78).
+        delta_flow `[B,2,H,W]` in fp32 / fp16 / bf16 as the flow head returns it (promoted to fp32 like torch's
+        `+`).  Returns `(coords1_new, flow, activation)`."""
+        if torch.is_grad_enabled() and (self._token is not None or weight.requires_grad or bias.requires_grad
+                                        or (delta_flow is not None and delta_flow.requires_grad)):
+            raise RuntimeError("update_lookup_convc1 is forward-only: call it under torch.no_grad()")
+        if self.radius > _lib.RC_CONVC1_MAX_RADIUS:
+            raise ValueError(f"lookup_convc1 supports radius <= {_lib.RC_CONVC1_MAX_RADIUS}")
+        coords1 = _check_coords(coords1, self.B, self.H, self.W1, self.device)
+        dptr, ddt = None, _lib.RC_F32
+        if delta_flow is not None:
+            if tuple(delta_flow.shape) != (self.B, 2, self.H, self.W1) or delta_flow.device != self.device:
+                raise ValueError(f"delta_flow must be [B={self.B}, 2, H={self.H}, W={self.W1}] on {self.device}")
+            delta = delta_flow.detach()
+            if delta.dtype not in _DT:
+                delta = delta.float()
+            delta = delta.contiguous()
+            dptr, ddt = delta.data_ptr(), _DT[delta.dtype]
+        with _on_device(self.device):
+            st = _stream(self.device)
+            self._pack_convc1(weight, bias, st)
+            new = torch.empty((self.B, 2, self.H, self.W1), dtype=torch.float32, device=self.device)
+            flow = torch.empty_like(new)
+            out = torch.empty((self.B, _lib.RC_CONVC1_OUT, self.H, self.W1), dtype=self.volume_torch_dtype,
+                              device=self.device)
+            check(lib.rc_lookup_convc1_fwd_update(self._vol_ptr, self._lay_ref, coords1.data_ptr(), coords1.shape[1],
+                                                  dptr, ddt, new.data_ptr(), flow.data_ptr(),
+                                                  self._convc1_packed.data_ptr(), self._convc1_bias.data_ptr(),
+                                                  out.data_ptr(), self.radius, self.coord_mode, int(bool(relu)), st),
+                  "rc_lookup_convc1_fwd_update")
+        return new, flow, out
+
+    def _pack_convc1(self, weight, bias, st):
+        """convc1's weight in MFMA fragment order, cached while the parameters stand still."""
         K = self.num_levels * (2 * self.radius + 1)
+        if weight.numel() != _lib.RC_CONVC1_OUT * K or weight.shape[0] != _lib.RC_CONVC1_OUT \
+                or bias.numel() != _lib.RC_CONVC1_OUT:
+            raise ValueError(f"convc1 weight must be [{_lib.RC_CONVC1_OUT}, {K}(,1,1)] and bias "
+                             f"[{_lib.RC_CONVC1_OUT}], got {tuple(weight.shape)} and {tuple(bias.shape)}")
+        if weight.device != self.device or bias.device != self.device:
+            raise RuntimeError("convc1 parameters live on a different device than the feature maps")
         try:
             key = (weight.data_ptr(), weight._version, bias.data_ptr(), bias._version)
         except RuntimeError:      # inference-mode tensors have no version counter: re-pack on every call
             key = None
+        if key is None or getattr(self, "_convc1_key", None) != key:
+            w32 = weight.detach().reshape(_lib.RC_CONVC1_OUT, K).float().contiguous()
+            self._convc1_packed = torch.empty(_lib.RC_CONVC1_OUT * 64, dtype=self.volume_torch_dtype,
+                                              device=self.device)
+            check(lib.rc_convc1_pack(w32.data_ptr(), self.num_levels, self.radius, self.vol_dtype,
+                                     self._convc1_packed.data_ptr(), st), "rc_convc1_pack")
+            self._convc1_bias = bias.detach().float().contiguous().clone()
+            self._convc1_key = key
+
+    def _lookup_convc1(self, coords, weight, bias, relu):
+        K = self.num_levels * (2 * self.radius + 1)
         with torch.cuda.device(self.device):
             st = _stream(self.device)
-            if key is None or getattr(self, "_convc1_key", None) != key:
-                w32 = weight.detach().reshape(_lib.RC_CONVC1_OUT, K).float().contiguous()
-                self._convc1_packed = torch.empty(_lib.RC_CONVC1_OUT * 64, dtype=self.volume_torch_dtype,
-                                                  device=self.device)
-                check(lib.rc_convc1_pack(w32.data_ptr(), self.num_levels, self.radius, self.vol_dtype,
-                                         self._convc1_packed.data_ptr(), st), "rc_convc1_pack")
-                self._convc1_bias = bias.detach().float().contiguous().clone()
-                self._convc1_key = key
+            self._pack_convc1(weight, bias, st)
             out = torch.empty((self.B, _lib.RC_CONVC1_OUT, self.H, self.W1), dtype=self.volume_torch_dtype,
                               device=self.device)
             check(lib.rc_lookup_convc1_fwd(self._vol_ptr, self._lay_ref, coords.data_ptr(), coords.shape[1],

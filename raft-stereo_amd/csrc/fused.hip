@@ -142,6 +142,15 @@ __device__ __forceinline__ void transpose_rows(uint32_t (&r)[4]) {
   swap32u(r[1], r[3]);
 }
 
+// Optional coordinate update in front of the fused lookup (rc_lookup_convc1_fwd_update): coords_out == null for a
+// plain rc_lookup_convc1_fwd
+struct fc_update {
+  const void* delta;   // [B,2,H,W1] in delta_dtype, channel 0 is added to x (null: nothing is added)
+  int delta_dtype;     // RC_F32 / RC_F16 / RC_BF16
+  float* coords_out;   // [B,2,H,W1]
+  float* flow_out;     // [B,2,H,W1]
+};
+
 // TILE: 16-bit outputs made of whole 16-byte pieces (decided by the launcher) leave through the LDS tile
 template <typename VT, int R, int MODE, bool TILE>
 __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __restrict__ vol, rc_dev_layout lay,
@@ -150,7 +159,7 @@ __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __r
                                                                    const VT* __restrict__ wpack,
                                                                    const float* __restrict__ bias,
                                                                    VT* __restrict__ out, int chunks_per_image,
-                                                                   int n_items, int relu, int nts) {
+                                                                   int n_items, int relu, int nts, fc_update upd) {
   constexpr bool IS16 = sizeof(VT) == 2;
   using PF = pair_fetch<VT, R, MODE>;
   using SF = single_fetch<VT, R, MODE>;
@@ -180,7 +189,25 @@ __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __r
   const int L = lay.L;
 
   // ---- phase 1: the plain lookup's gather, one pixel per lane: taps of every level in registers
-  const float x = (coords + uniform(((int64_t)b * coords_channels) * HW))[min(it.p0 + poff, (int)HW - 1)];
+  const int pidx = min(it.p0 + poff, (int)HW - 1);
+  float x = (coords + uniform(((int64_t)b * coords_channels) * HW))[pidx];
+  if (upd.coords_out) {  // wave-uniform: the GRU iteration's coordinate glue (core/raft_stereo.py:109-111, :120-123)
+    const int64_t q0 = uniform(((int64_t)b * 2) * HW);
+    if (upd.delta) {  // coords1 = coords1 + (delta_flow[:,0], 0): the fp32 add of the reference (delta promoted)
+      float dlt;
+      if (upd.delta_dtype == RC_F32) dlt = (reinterpret_cast<const float*>(upd.delta) + q0)[pidx];
+      else if (upd.delta_dtype == RC_F16) dlt = (float)(reinterpret_cast<const rc_half*>(upd.delta) + q0)[pidx];
+      else dlt = (float)(reinterpret_cast<const rc_bf16*>(upd.delta) + q0)[pidx];
+      x += dlt;
+    }
+    const float y = coords_channels > 1 ? (coords + uniform(((int64_t)b * coords_channels + 1) * HW))[pidx] : (float)h;
+    if (it.p0 + poff < (int)HW) {  // lanes past the end of the image repeat its last pixel and store nothing
+      (upd.coords_out + q0)[pidx] = x;
+      (upd.coords_out + uniform(q0 + HW))[pidx] = y;
+      (upd.flow_out + q0)[pidx] = x - (float)w1g;   // flow = coords1 - coords0, coords0 = the pixel grid
+      (upd.flow_out + uniform(q0 + HW))[pidx] = y - (float)h;
+    }
+  }
   float tap[RC_MAX_LEVELS][NT];
   uint32_t pk[RC_MAX_LEVELS][NDW];  // 16-bit pyramids: the taps rounded to the pyramid's type, two per dword
 #pragma unroll
@@ -425,7 +452,7 @@ __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __r
 
 template <typename VT, int R>
 int launch_fused(const void* vol, rc_dev_layout d, const float* coords, int cc, const void* wpack,
-                 const float* bias, void* out, int mode, int relu, hipStream_t st) {
+                 const float* bias, void* out, int mode, int relu, hipStream_t st, const fc_update& upd) {
   constexpr int WPB = FC_THREADS / 64;
   const int chunks = (d.H * d.W1 + FC_THREADS - 1) / FC_THREADS * WPB;  // whole blocks per image
   const int n_items = (int)((int64_t)d.B * chunks);
@@ -441,7 +468,7 @@ int launch_fused(const void* vol, rc_dev_layout d, const float* coords, int cc, 
     set_row_bias(d, vt_info<VT>::RB, pair_info<vt_info<VT>::RB, R, MODE>::NW2);                               \
     hipLaunchKernelGGL((lookup_convc1_kernel<VT, R, MODE, TILE>), dim3(blocks), dim3(FC_THREADS), 0, st,       \
                        (const VT*)vol, d, coords, cc, (const VT*)wpack, bias, (VT*)out, chunks, n_items, relu, \
-                       nts);                                                                                   \
+                       nts, upd);                                                                              \
   } while (0)
   if constexpr (IS16) {
     if (tile) {
@@ -458,15 +485,15 @@ int launch_fused(const void* vol, rc_dev_layout d, const float* coords, int cc, 
 
 template <typename VT>
 int dispatch_fused(const void* vol, const rc_dev_layout& d, const float* coords, int cc, const void* wpack,
-                   const float* bias, void* out, int radius, int mode, int relu, hipStream_t st) {
+                   const float* bias, void* out, int radius, int mode, int relu, hipStream_t st, const fc_update& upd) {
   switch (radius) {
-    case 1: return launch_fused<VT, 1>(vol, d, coords, cc, wpack, bias, out, mode, relu, st);
-    case 2: return launch_fused<VT, 2>(vol, d, coords, cc, wpack, bias, out, mode, relu, st);
-    case 3: return launch_fused<VT, 3>(vol, d, coords, cc, wpack, bias, out, mode, relu, st);
-    case 4: return launch_fused<VT, 4>(vol, d, coords, cc, wpack, bias, out, mode, relu, st);
-    case 5: return launch_fused<VT, 5>(vol, d, coords, cc, wpack, bias, out, mode, relu, st);
-    case 6: return launch_fused<VT, 6>(vol, d, coords, cc, wpack, bias, out, mode, relu, st);
-    case 7: return launch_fused<VT, 7>(vol, d, coords, cc, wpack, bias, out, mode, relu, st);
+    case 1: return launch_fused<VT, 1>(vol, d, coords, cc, wpack, bias, out, mode, relu, st, upd);
+    case 2: return launch_fused<VT, 2>(vol, d, coords, cc, wpack, bias, out, mode, relu, st, upd);
+    case 3: return launch_fused<VT, 3>(vol, d, coords, cc, wpack, bias, out, mode, relu, st, upd);
+    case 4: return launch_fused<VT, 4>(vol, d, coords, cc, wpack, bias, out, mode, relu, st, upd);
+    case 5: return launch_fused<VT, 5>(vol, d, coords, cc, wpack, bias, out, mode, relu, st, upd);
+    case 6: return launch_fused<VT, 6>(vol, d, coords, cc, wpack, bias, out, mode, relu, st, upd);
+    case 7: return launch_fused<VT, 7>(vol, d, coords, cc, wpack, bias, out, mode, relu, st, upd);
   }
   rc_set_error("fused lookup + convc1: radius %d outside 1..%d", radius, RC_CONVC1_MAX_RADIUS);
   return RC_EUNSUPPORTED;
@@ -502,9 +529,9 @@ extern "C" int rc_convc1_pack(const float* weight, int num_levels, int radius, i
   return rc_check_launch("rc_convc1_pack");
 }
 
-extern "C" int rc_lookup_convc1_fwd(const void* vol, const rc_layout* lay, const float* coords,
-                                    int coords_channels, const void* packed_weight, const float* bias, void* out,
-                                    int radius, int coord_mode, int relu, void* stream) {
+static int fused_any(const void* vol, const rc_layout* lay, const float* coords, int coords_channels,
+                     const void* packed_weight, const float* bias, void* out, int radius, int coord_mode, int relu,
+                     void* stream, const fc_update& upd) {
   RC_REQUIRE(packed_weight && bias, RC_EINVAL, "null pointer argument");
   RC_REQUIRE(radius <= RC_CONVC1_MAX_RADIUS, RC_EUNSUPPORTED, "fused lookup + convc1: radius %d outside 1..%d",
              radius, RC_CONVC1_MAX_RADIUS);
@@ -520,14 +547,33 @@ extern "C" int rc_lookup_convc1_fwd(const void* vol, const rc_layout* lay, const
   switch (lay->dtype) {
     case RC_F32:
       return dispatch_fused<float>(vol, d, coords, coords_channels, packed_weight, bias, out, radius, coord_mode,
-                                   relu, st);
+                                   relu, st, upd);
     case RC_F16:
       return dispatch_fused<rc_half>(vol, d, coords, coords_channels, packed_weight, bias, out, radius, coord_mode,
-                                     relu, st);
+                                     relu, st, upd);
     case RC_BF16:
       return dispatch_fused<rc_bf16>(vol, d, coords, coords_channels, packed_weight, bias, out, radius, coord_mode,
-                                     relu, st);
+                                     relu, st, upd);
   }
   rc_set_error("unknown pyramid dtype %d", lay->dtype);
   return RC_EUNSUPPORTED;
+}
+
+extern "C" int rc_lookup_convc1_fwd(const void* vol, const rc_layout* lay, const float* coords,
+                                    int coords_channels, const void* packed_weight, const float* bias, void* out,
+                                    int radius, int coord_mode, int relu, void* stream) {
+  const fc_update none = {nullptr, RC_F32, nullptr, nullptr};
+  return fused_any(vol, lay, coords, coords_channels, packed_weight, bias, out, radius, coord_mode, relu, stream, none);
+}
+
+extern "C" int rc_lookup_convc1_fwd_update(const void* vol, const rc_layout* lay, const float* coords,
+                                           int coords_channels, const void* delta_flow, int delta_dtype,
+                                           float* coords_out, float* flow_out, const void* packed_weight,
+                                           const float* bias, void* out, int radius, int coord_mode, int relu,
+                                           void* stream) {
+  RC_REQUIRE(coords_out && flow_out, RC_EINVAL, "null pointer argument");
+  RC_REQUIRE(delta_dtype == RC_F32 || delta_dtype == RC_F16 || delta_dtype == RC_BF16, RC_EUNSUPPORTED,
+             "unknown delta_flow dtype %d", delta_dtype);
+  const fc_update upd = {delta_flow, delta_dtype, coords_out, flow_out};
+  return fused_any(vol, lay, coords, coords_channels, packed_weight, bias, out, radius, coord_mode, relu, stream, upd);
 }

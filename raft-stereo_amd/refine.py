@@ -35,6 +35,26 @@ def refine_disparity(update_block, corr_fn, net_list, inp_list, args, iters=12, 
         and hasattr(corr_fn, "lookup_convc1") and corr_fn.radius <= 7
     net_list = list(net_list)
     predictions, flow_up = [], None
+    if fuse and test_mode and not torch.is_grad_enabled() and hasattr(corr_fn, "update_lookup_convc1"):
+        # inference: an iteration's glue costs no launch of its own -- `coords1 += (delta_x, 0)` of the previous
+        # iteration, `flow = coords1 - coords0` and relu(convc1(lookup(coords1))) are one kernel
+        # (raft_stereo.py:109-111, :120-123; update.py:78), bit-identical to the separate steps
+        enc = getattr(update_block, "module", update_block).encoder
+        delta_flow = None
+        for itr in range(iters):
+            coords1, flow, act = corr_fn.update_lookup_convc1(coords1, delta_flow, enc.convc1.weight, enc.convc1.bias)
+            with torch.autocast("cuda", enabled=amp):
+                if layers == 3 and slow_fast:
+                    net_list = update_block(net_list, inp_list, iter32=True, iter16=False, iter08=False, update=False)
+                if layers >= 2 and slow_fast:
+                    net_list = update_block(net_list, inp_list, iter32=layers == 3, iter16=True, iter08=False,
+                                            update=False)
+                net_list, up_mask, delta_flow = update_block(net_list, inp_list, flow=flow, iter32=layers == 3,
+                                                             iter16=layers >= 2, act=act)
+        # the last iteration's update, in the reference's order of operations (once per pass)
+        coords1 = coords1 + torch.cat([delta_flow[:, :1], torch.zeros_like(delta_flow[:, :1])], dim=1)
+        final = coords1 - coords0
+        return final, upsample_flow_hip(final, up_mask, args.n_downsample, channels=1)
     for itr in range(iters):
         coords1 = coords1.detach()                                     # raft_stereo.py:109
         flow = coords1 - coords0

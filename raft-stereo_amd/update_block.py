@@ -4,7 +4,7 @@ package's kernels (core/update.py:64-138 of the reference).
     BasicMultiUpdateBlockHip(args, hidden_dims)     same constructor and parameter names as
                                                     BasicMultiUpdateBlock (a reference state_dict loads as is)
         .forward(net, inp, corr=None, flow=None, iter08=True, iter16=True, iter32=True, update=True,
-                 corr_fn=None, coords=None)
+                 corr_fn=None, coords=None, act=None)
 
 What runs in the HIP library: the three ConvGRUs' gate arithmetic (ConvGRUHip) and, when the caller hands
 over the correlation block and the coordinates instead of a looked-up `corr` tensor, the lookup fused with
@@ -43,11 +43,16 @@ class MotionEncoderHip(nn.Module):
         self.convf2 = nn.Conv2d(64, 64, 3, padding=1)
         self.conv = nn.Conv2d(128, 126, 3, padding=1)
 
-    def forward(self, flow, corr=None, corr_fn=None, coords=None):
+    def forward(self, flow, corr=None, corr_fn=None, coords=None, act=None):
+        """`act`: relu(convc1(lookup)) already computed by the caller (the refinement loop folds the coordinate
+        update into the same kernel: CorrBlock1DHip.update_lookup_convc1)."""
         if corr is None:
-            if corr_fn is None or coords is None:
-                raise ValueError("pass either corr or (corr_fn, coords)")
-            c = corr_fn.lookup_convc1(coords, self.convc1.weight, self.convc1.bias)
+            if act is not None:
+                c = act
+            elif corr_fn is None or coords is None:
+                raise ValueError("pass either corr, act or (corr_fn, coords)")
+            else:
+                c = corr_fn.lookup_convc1(coords, self.convc1.weight, self.convc1.bias)
             if not torch.is_autocast_enabled():       # a 16-bit pyramid under an fp32 update block
                 c = c.to(self.convc2.weight.dtype)
         else:
@@ -89,7 +94,7 @@ class BasicMultiUpdateBlockHip(nn.Module):
                                   nn.Conv2d(256, f * f * 9, 1, padding=0))
 
     def forward(self, net, inp, corr=None, flow=None, iter08=True, iter16=True, iter32=True, update=True,
-                corr_fn=None, coords=None):
+                corr_fn=None, coords=None, act=None):
         layers = self.args.n_gru_layers
         if iter32:
             net[2] = self.gru32(net[2], *inp[2], _down2(net[1]))
@@ -97,7 +102,7 @@ class BasicMultiUpdateBlockHip(nn.Module):
             extra = [_down2(net[0])] + ([_resize_like(net[2], net[1])] if layers > 2 else [])
             net[1] = self.gru16(net[1], *inp[1], *extra)
         if iter08:
-            motion = self.encoder(flow, corr, corr_fn=corr_fn, coords=coords)
+            motion = self.encoder(flow, corr, corr_fn=corr_fn, coords=coords, act=act)
             extra = [motion] + ([_resize_like(net[1], net[0])] if layers > 1 else [])
             net[0] = self.gru08(net[0], *inp[0], *extra)
         if not update:

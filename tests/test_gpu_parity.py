@@ -863,6 +863,46 @@ def test_update_and_lookup_is_bit_identical_to_the_separate_steps(R, dtype, shap
         assert torch.equal(corr, blk(new))
 
 
+@pytest.mark.parametrize("dtype,shape,ddt", [(torch.float32, (2, 64, 3, 45), torch.float32),
+                                              (torch.float16, (2, 256, 7, 312), torch.float16),
+                                              (torch.float16, (1, 256, 60, 80), torch.float32),
+                                              (torch.bfloat16, (1, 32, 2, 130), torch.bfloat16)])
+def test_update_lookup_convc1_is_bit_identical_to_the_separate_steps(R, dtype, shape, ddt):
+    """core/raft_stereo.py:109-111,120-123 + core/update.py:78: one kernel (rc_lookup_convc1_fwd_update) against
+    torch's coordinate arithmetic followed by the fused lookup + convc1.  The flow head's delta arrives in the
+    autocast dtype and is promoted to fp32 by torch's `+`; the first iteration has no delta."""
+    gen = torch.Generator(device="cuda").manual_seed(23)
+    B, D, H, W = shape
+    f1 = torch.randn(shape, generator=gen, device="cuda").to(dtype)
+    f2 = torch.randn(shape, generator=gen, device="cuda").to(dtype)
+    w = torch.randn((64, 36, 1, 1), generator=gen, device="cuda") * 0.2
+    bias = torch.randn((64,), generator=gen, device="cuda")
+    coords1 = torch.from_numpy(O.synthetic_coords(B, H, W, seed=9)).cuda()
+    ys, xs = torch.meshgrid(torch.arange(H, device="cuda"), torch.arange(W, device="cuda"), indexing="ij")
+    coords0 = torch.stack([xs, ys], dim=0).float()[None].repeat(B, 1, 1, 1)
+    with torch.no_grad():
+        blk = R.CorrBlock1DHip(f1, f2)
+        delta = None
+        for it in range(3):
+            if delta is None:
+                ref_coords = coords1
+            else:
+                ref_delta = delta.clone()
+                ref_delta[:, 1] = 0.0
+                ref_coords = coords1 + ref_delta                 # fp32 + 16-bit promotes to fp32
+            assert ref_coords.dtype == torch.float32
+            ref_act, ref_flow = blk.lookup_convc1(ref_coords, w, bias), ref_coords - coords0
+            new, flow, act = blk.update_lookup_convc1(coords1, delta, w, bias)
+            assert torch.equal(new, ref_coords) and torch.equal(flow, ref_flow) and torch.equal(act, ref_act)
+            coords1 = new
+            delta = (torch.randn((B, 2, H, W), generator=gen, device="cuda") * 2.5).to(ddt)
+        new, flow, act = blk.update_lookup_convc1(coords1[:, :1].contiguous(), delta, w, bias, relu=False)
+        assert torch.equal(new[:, 1], coords0[:, 1]) and torch.equal(flow[:, 1], torch.zeros_like(flow[:, 1]))
+        assert torch.equal(act, blk.lookup_convc1(new, w, bias, relu=False))
+    with pytest.raises(RuntimeError):       # forward-only
+        R.CorrBlock1DHip(f1.requires_grad_(True), f2).update_lookup_convc1(coords1, None, w, bias)
+
+
 # ------------------------------------------------------------------ HIP graph capture
 def test_build_and_lookups_replay_from_a_hip_graph(R):
     """The library neither allocates nor synchronises, so a caller can capture its GRU loop: the
@@ -974,3 +1014,38 @@ def test_argument_errors(R):
     both = torch.randn(2, 32, 2, 32, device="cuda")
     a, b = both.split(1, dim=0)
     R.CorrBlock1DHip(a.transpose(2, 3).transpose(2, 3), b)(torch.zeros(1, 2, 2, 32, device="cuda"))
+
+
+def test_training_step_frees_the_pyramid_without_the_cyclic_collector(R):
+    """The build node of the autograd graph holds its block weakly (block -> token -> node -> ctx -> block was a
+    reference cycle): after a training step, dropping the block and its outputs must return every byte to
+    torch's allocator by reference counting alone, with Python's cyclic collector switched off."""
+    import gc
+    g = torch.Generator(device="cuda").manual_seed(3)
+    f1 = torch.randn((2, 256, 24, 96), generator=g, device="cuda").half().requires_grad_(True)
+    f2 = torch.randn((2, 256, 24, 96), generator=g, device="cuda").half().requires_grad_(True)
+    coords = dev(O.synthetic_coords(2, 24, 96, seed=2))
+
+    def step():
+        blk = R.CorrBlock1DHip(f1, f2, num_levels=4, radius=4)
+        outs = [blk(coords), blk(coords + 0.25), blk.lookup_convc1(coords, torch.randn(64, 36, device="cuda"),
+                                                                    torch.randn(64, device="cuda")).float().mean(1, keepdim=True)]
+        sum(o.sum() for o in outs).backward()
+        f1.grad = f2.grad = None
+
+    step()                              # warm-up: allocator pools, library workspaces
+    gc.collect()
+    torch.cuda.synchronize()
+    gc.disable()
+    try:
+        base = torch.cuda.memory_allocated()
+        step()
+        torch.cuda.synchronize()
+        assert torch.cuda.memory_allocated() == base
+        # forward only, gradients enabled, no backward: nothing may wait for the collector either
+        blk = R.CorrBlock1DHip(f1, f2, num_levels=4, radius=4)
+        out = blk(coords)
+        del blk, out
+        assert torch.cuda.memory_allocated() == base
+    finally:
+        gc.enable()

@@ -63,6 +63,10 @@ def main(src, dst):
         if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
             v["traffic_bytes_raw"] = (v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0
             v["traffic_bytes_corrected"] = (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0
+        # gfx950's size-aware read counter (a 128-byte request counts 4): the bytes read from memory without any
+        # correction; tools/lab_sector.hip shows it at 4 per line whatever part of a line was asked for
+        if "TCC_EA0_RDREQ_DRAM_32B_sum" in v:
+            v["read_bytes_dram_32b"] = 32.0 * v["TCC_EA0_RDREQ_DRAM_32B_sum"]
     json.dump(keep, open(dst, "w"), indent=1, sort_keys=True)
     for k, v in sorted(keep.items()):
         print(k, json.dumps({a: (round(b, 1) if isinstance(b, float) else b) for a, b in sorted(v.items())}))

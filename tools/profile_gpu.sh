@@ -18,6 +18,7 @@ run sq --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY
 run sq2 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT &&
 run tcc --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_HIT_sum TCC_MISS_sum &&
 run tcc2 --pmc TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_64B_sum TCC_REQ_sum TCC_READ_sum &&
+run tcc3 --pmc TCC_EA0_RDREQ_DRAM_32B_sum TCC_EA0_RD_UNCACHED_32B_sum &&
 run fetch --pmc FETCH_SIZE &&
 run write --pmc WRITE_SIZE &&
 run tcp --pmc TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TOTAL_ACCESSES_sum TA_BUSY_avr TA_TA_BUSY_sum GRBM_GUI_ACTIVE
