@@ -16,12 +16,30 @@
 #include "rc_common.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <type_traits>
 
 // Ablation switches for tools/lab_build.hip only (the library is built with 0): 1 = no pyramid stores,
 // 2 = no MFMA, 4 = no f2 loads after the first two chunks
 #ifndef RC_LAB_ABLATE
 #define RC_LAB_ABLATE 0
+#endif
+
+// Phase stamps for tools/lab_build.hip only (the library is built without): s_memtime at the phase boundaries
+// of every wave of build16_kernel, into a buffer of their own that nothing else reads
+#ifdef RC_LAB_STAMPS
+constexpr int RC_LAB_NSTAMP = 32;
+__device__ unsigned long long rc_lab_stamps[4096 * 8 * RC_LAB_NSTAMP];
+#define RC_STAMP(slot)                                                                                              \
+  do {                                                                                                              \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096 && (slot) < RC_LAB_NSTAMP)                                     \
+      rc_lab_stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * RC_LAB_NSTAMP + (slot)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+extern "C" int rc_lab_read_stamps(unsigned long long* dst, size_t n) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(rc_lab_stamps), n * sizeof(unsigned long long));
+}
+#else
+#define RC_STAMP(slot) do {} while (0)
 #endif
 
 namespace {
@@ -363,6 +381,7 @@ __global__ __launch_bounds__(BT16, 4) void build16_kernel(const T* __restrict__ 
   T* const buf1 = ldsF + C::LDS_BYTES / (int)sizeof(T);
   u4v regs[2][NP];
   s8v bfrag[C::NKS];
+  RC_STAMP(0);
   {
     // both halves (64 columns each) of the f1 tile and the first two f2 chunks are requested before anything is
     // waited for; the halves go through the two staging buffers side by side
@@ -371,16 +390,21 @@ __global__ __launch_bounds__(BT16, 4) void build16_kernel(const T* __restrict__ 
     stage_load<T, FAST, NP>(fb, f1row, ks1, W1, c0 + 64, D);
     stage_load<T, FAST, NP>(regs[0], f2row, ks2, W2, 0, D);
     if (n_chunks > 1) stage_load<T, FAST, NP>(regs[1], f2row, ks2, W2, C::TN, D);
+    RC_STAMP(1);
     stage_store<T, C::PF, NP>(fa, buf0);
     stage_store<T, C::PF, NP>(fb, buf1);
+    RC_STAMP(2);
     __syncthreads();
+    RC_STAMP(3);
     const short* src = reinterpret_cast<const short*>((wave >> 2) ? buf1 : buf0);
 #pragma unroll
     for (int kb = 0; kb < C::NKS; ++kb)
       bfrag[kb] = kb < nk ? tr_frag<C::PF>(src, kb, (wave & 3) * TW16) : (s8v)(0);
     __syncthreads();  // the fragments have been read: the buffers are free for f2
+    RC_STAMP(4);
     stage_store<T, C::PF, NP>(regs[0], buf0);
     if (n_chunks > 2) stage_load<T, FAST, NP>(regs[0], f2row, ks2, W2, 2 * C::TN, D);
+    RC_STAMP(5);
   }
 
   out_map<T> om;
@@ -402,6 +426,7 @@ __global__ __launch_bounds__(BT16, 4) void build16_kernel(const T* __restrict__ 
   auto chunk = [&](u4v (&nxt)[NP], int c, const T* cur_buf, T* nxt_buf) {
     const int n0 = c * C::TN;
     __syncthreads();  // chunk c is in cur_buf; everybody is done reading nxt_buf (chunk c - 1)
+    RC_STAMP(6 + 4 * c);
     const bool active = cw < W1;  // wave-uniform: a wave past the row end only helps with the staging
     f4v acc[4];
 #pragma unroll
@@ -421,16 +446,300 @@ __global__ __launch_bounds__(BT16, 4) void build16_kernel(const T* __restrict__ 
         }
       }
     }
+    RC_STAMP(7 + 4 * c);
     if (c + 1 < n_chunks) {
       stage_store<T, C::PF, NP>(nxt, nxt_buf);
       if (c + 3 < n_chunks && !(RC_LAB_ABLATE & 4)) stage_load<T, FAST, NP>(nxt, f2row, ks2, W2, n0 + 3 * C::TN, D);
     }
+    RC_STAMP(8 + 4 * c);
     if (active) epilogue16_col<T>(acc, scale, om, L, n0, cw);
+    RC_STAMP(9 + 4 * c);
   };
   for (int c = 0; c < n_chunks; c += 2) {
     chunk(regs[1], c, buf0, buf1);
     if (c + 1 < n_chunks) chunk(regs[0], c + 1, buf1, buf0);
   }
+}
+
+// ---- 16-bit feature maps whose rows are whole 16-byte segments (W1, W2 multiples of 8, D = 256): the f2 stream and
+// the f1 tile go global -> LDS by LDS-DMA (global_load_lds_dwordx4), no staging registers and no ds_write pass.
+// That frees the registers for 32-column wave tiles: 8 waves = 4 column groups x 2 halves of the 64-row chunk,
+// every f2 fragment read from LDS feeds TWO MFMAs (the 16-column kernel above reads every fragment for one: its
+// MFMA phase is bound by LDS bandwidth, 2 200 cycles per chunk where the matrix pipe needs 1 000:
+// profiles/r03/lab_build_stamps.txt).  A DMA instruction writes 1 KiB of LDS in lane order, so a staged tile is
+// [256 k][128 bytes] without padding; bank conflicts of the transposed reads are avoided by an XOR swizzle of
+// the 16-byte segments, applied on the SOURCE side of the DMA (each lane fetches the segment its slot holds):
+//     physical segment = segment ^ (((k >> 1) & 3) << 1).
+// Stores are range-checked buffer stores (cells outside the image get an out-of-range offset and are dropped):
+// every wave issues the same number of store instructions per chunk, which is what lets a COUNTED s_waitcnt
+// vmcnt(n) wait for the chunk's DMA without waiting for the stores issued after it.
+constexpr int G_ROW = 128;           // bytes per LDS row: 64 elements
+constexpr int G_BUF = KMAX * G_ROW;  // one staged tile: 32 KiB
+
+// one DMA instruction: lane l fetches 16 bytes from gsrc, they land at lds_dst + 16 l (lds_dst wave-uniform)
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+
+// [256 k][64 columns from n0] of one image row -> the LDS tile at byte address lds_buf: 4 DMA instructions per
+// wave, instruction p of wave w fills rows 64 p + 8 w .. + 7.  Segments past the end of the row re-read its start
+// (what they produce lands in padding cells or in columns that are not stored).
+template <typename T>
+__device__ __forceinline__ void dma_tile(const T* rowbase, int64_t kstride, int W, int n0, uint32_t lds_buf, int wave) {
+  const int lane = threadIdx.x & 63;
+  const int kr = lane >> 3;
+  const int ls = (lane & 7) ^ (((kr >> 1) & 3) << 1);  // the logical segment this lane's slot holds
+  int col = n0 + ls * 8;
+  col = col >= W ? 0 : col;
+  const T* src = rowbase + (int64_t)(wave * 8 + kr) * kstride + col;
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+    glds16(src + (int64_t)p * 64 * kstride, lds_buf + (uint32_t)((p * 64 + wave * 8) * G_ROW));
+}
+
+// byte offset inside a swizzled tile of this lane's transposed-read address for the 16 columns from `co`
+// (a multiple of 16), k block 0; k block kb adds 4096 kb, the second half of a fragment 2048
+__device__ __forceinline__ uint32_t frag_off(int co) {
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, i = lane & 15;
+  const int kl = 4 * g + (i >> 2);
+  const int sw = ((kl >> 1) & 3) << 1;
+  const int seg = (co >> 3) + ((i >> 1) & 1);
+  return (uint32_t)(kl * G_ROW + ((seg ^ sw) << 4) + (i & 1) * 8);
+}
+__device__ __forceinline__ s8v tr_frag_g(const unsigned char* tile, uint32_t off, int kb) {
+  typedef s4v __attribute__((address_space(3))) * lds_s4p;
+  const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(tile + off + kb * 4096));
+  const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(tile + off + kb * 4096 + 2048));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// pooled pair: round(0.5 * (lo(x0) + hi(x0))) | round(0.5 * (lo(x1) + hi(x1))) << 16 -- the fp32 mean of two stored
+// values rounded once, what avg_pool2d does on a 16-bit volume.  fp16: the mixed-precision FMA reads the halves
+// directly (sum = lo * 1.0 + hi in fp32, one instruction instead of two conversions and an add) and v_fma_mixlo/hi
+// scale, round and pack in one (0.5 * sum is exact, so this is the same single rounding)
+template <typename VT> __device__ __forceinline__ uint32_t mean_pair(uint32_t x0, uint32_t x1) {
+  return pack2<VT>(0.5f * (unpack_lo<VT>(x0) + unpack_hi<VT>(x0)), 0.5f * (unpack_lo<VT>(x1) + unpack_hi<VT>(x1)));
+}
+template <> __device__ __forceinline__ uint32_t mean_pair<rc_half>(uint32_t x0, uint32_t x1) {
+  float s0, s1;
+  uint32_t r;
+  asm("v_fma_mix_f32 %0, %1, 1.0, %1 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(s0) : "v"(x0));
+  asm("v_fma_mix_f32 %0, %1, 1.0, %1 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(s1) : "v"(x1));
+  asm("v_fma_mixlo_f16 %0, %1, 0.5, 0 op_sel_hi:[0,0,0]\n\tv_fma_mixhi_f16 %0, %2, 0.5, 0 op_sel_hi:[0,0,0]"
+      : "=&v"(r)
+      : "v"(s0), "v"(s1));
+  return r;
+}
+
+// one stored level of one image row, as a range-checked buffer
+struct out_slab {
+  __amdgpu_buffer_rsrc_t rs;
+  uint32_t bytes, nb, kb;
+};
+// 16-byte block of group G of pixel `col` at the slab's level (shift `i`); cells outside the image are dropped
+template <int I>
+__device__ __forceinline__ void slab_store16(const out_slab& sl, uint32_t blk_bytes, int W1, int col, int G, uint32_t a,
+                                             uint32_t b, uint32_t c, uint32_t d) {
+  uint32_t t = (uint32_t)(G - ((col >> I) >> 3)) + sl.kb;  // >= 0 by choice of bias
+  t = min(t, t - 2 * sl.nb);
+  t = min(t, t - sl.nb);
+  uint32_t off = __umul24(t, blk_bytes) + (uint32_t)col * 16u;
+  asm volatile("" : "+v"(off));  // computed for every lane: the select stays a v_cndmask
+  off = (col < W1 && (uint32_t)G < sl.nb) ? off : sl.bytes;
+  const u4v v = {a, b, c, d};
+  if constexpr (RC_LAB_ABLATE & 1) {
+    asm volatile("" ::"v"(v), "v"(off));
+    return;
+  }
+  __builtin_amdgcn_raw_buffer_store_b128(v, sl.rs, (int)off, 0, 2 /* nt */);
+}
+
+// epilogue of a 32 (w2) x 32 (w1) wave tile: acc[rt][ct], lane (g, li) holds rows n0 + 16 rt + 4 g + {0..3} of
+// column cw + 16 ct + li.  Exactly 2 (L < 3) or 3 store instructions.
+template <typename VT>
+__device__ __forceinline__ void epilogue16_g(const f4v (&acc)[2][2], float scale, const out_slab& s0, const out_slab& s2,
+                                             uint32_t blk_bytes, int W1, int L, int n0, int cw) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
+  const int col_sw = cw + 16 * (g & 1) + li;  // column a lane serves after a swap16 between the column tiles
+  uint32_t q1[2][2];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    uint32_t x[2][2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      x[ct][0] = pack2<VT>(acc[rt][ct][0] * scale, acc[rt][ct][1] * scale);
+      x[ct][1] = pack2<VT>(acc[rt][ct][2] * scale, acc[rt][ct][3] * scale);
+      q1[rt][ct] = mean_pair<VT>(x[ct][0], x[ct][1]);
+    }
+    swap16(x[0][0], x[1][0]);
+    swap16(x[0][1], x[1][1]);
+    slab_store16<0>(s0, blk_bytes, W1, col_sw, ((n0 + 16 * rt) >> 3) + (g >> 1), x[0][0], x[0][1], x[1][0], x[1][1]);
+  }
+  if (L < 3) return;  // level 1 is not stored; level 2 is its pairwise mean
+  uint32_t w[4];      // w[ct] = level-2 values of row tiles 0, 1: block elements g and 4 + g
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) w[ct] = mean_pair<VT>(q1[0][ct], q1[1][ct]);
+  w[2] = w[3] = 0u;
+  transpose_rows(w);  // lane row j < 2: w[p] = elements (p, 4 + p) of the block of column tile j
+  const uint32_t d0 = __builtin_amdgcn_perm(w[1], w[0], 0x05040100u), d1 = __builtin_amdgcn_perm(w[3], w[2], 0x05040100u);
+  const uint32_t d2 = __builtin_amdgcn_perm(w[1], w[0], 0x07060302u), d3 = __builtin_amdgcn_perm(w[3], w[2], 0x07060302u);
+  slab_store16<2>(s2, blk_bytes, g < 2 ? W1 : 0, col_sw, n0 >> 5, d0, d1, d2, d3);
+}
+
+template <typename T>
+__global__ __launch_bounds__(BT16, 4) void build16g_kernel(const T* __restrict__ f1, const T* __restrict__ f2,
+                                                           T* __restrict__ vol, rc_dev_layout lay, float scale,
+                                                           int n_tiles, int n_rows) {
+  using C = build_cfg<T>;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int id = blockIdx.x;  // XCD-aware mapping as in build16_kernel
+  const int j = id >> 3;
+  const int row = (j / n_tiles) * 8 + (id & 7);
+  const int tile = j % n_tiles;
+  if (row >= n_rows) return;
+  const int b = row / lay.H, h = row - b * lay.H;
+  const int c0 = tile * TM;
+  const int W1 = lay.W1, W2 = lay.W2, L = lay.L;
+  constexpr int D = KMAX;
+
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int cg = wave & 3, rh = wave >> 2;  // column group (32 columns), half of the chunk's rows
+  const int cw = c0 + cg * 32;
+  const bool active = cw < W1;  // wave-uniform: a wave past the row end only helps with the staging
+
+  const T* f1row = f1 + ((int64_t)b * D * lay.H + h) * W1;
+  const T* f2row = f2 + ((int64_t)b * D * lay.H + h) * W2;
+  const int64_t ks1 = (int64_t)lay.H * W1, ks2 = (int64_t)lay.H * W2;
+  const int n_chunks = (W2 + C::TN - 1) / C::TN;
+  typedef unsigned char __attribute__((address_space(3))) * lds_p;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_p)smem;  // LDS byte address of the dynamic allocation
+
+  RC_STAMP(0);
+  // ---- the first f2 chunk is requested into registers (the LDS buffers are busy with f1 until its fragments have
+  // been read), then the f1 tile: both halves (64 columns each) through the two buffers.  One memory round trip
+  // covers both.
+  u4v c0regs[4];
+  const int sseg = threadIdx.x & 7, skr = threadIdx.x >> 3;  // segment and row (of 64 per pass) this thread stages
+  {
+    int col = sseg * 8;
+    col = col >= W2 ? 0 : col;
+    const T* src = f2row + (int64_t)skr * ks2 + col;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) c0regs[p] = *reinterpret_cast<const u4v*>(src + (int64_t)p * 64 * ks2);
+  }
+  dma_tile<T>(f1row, ks1, W1, c0, lds0, wave);
+  dma_tile<T>(f1row, ks1, W1, c0 + 64, lds0 + G_BUF, wave);
+  RC_STAMP(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  RC_STAMP(2);
+  s8v bfrag[C::NKS][2];
+  {
+    const unsigned char* src = smem + (cg >> 1) * G_BUF;
+    const uint32_t o0 = frag_off((cg & 1) * 32), o1 = frag_off((cg & 1) * 32 + 16);
+#pragma unroll
+    for (int kb = 0; kb < C::NKS; ++kb) {
+      bfrag[kb][0] = tr_frag_g(src, o0, kb);
+      bfrag[kb][1] = tr_frag_g(src, o1, kb);
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();  // the fragments have been read: the buffers are free for f2
+  RC_STAMP(3);
+  {
+    // chunk 0 from its registers into buffer 0 (same swizzle as the DMA's), then chunk 1 by DMA into buffer 1
+    unsigned char* dst = smem + skr * G_ROW + ((sseg ^ (((skr >> 1) & 3) << 1)) << 4);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) *reinterpret_cast<u4v*>(dst + p * 64 * G_ROW) = c0regs[p];
+  }
+  if (n_chunks > 1) dma_tile<T>(f2row, ks2, W2, C::TN, lds0 + G_BUF, wave);
+  RC_STAMP(4);
+
+  const uint32_t blk_bytes = (uint32_t)lay.pitch * 16u;
+  out_slab s0, s2;
+  {
+    const int nb0 = lay.widthp[0] >> 3, nb2 = lay.widthp[L > 2 ? 2 : 0] >> 3;
+    s0.nb = (uint32_t)nb0;
+    s0.kb = (uint32_t)(lay.bias[0] - RC_WRAP_ROWS / 8);
+    s0.bytes = (uint32_t)nb0 * blk_bytes;
+    s0.rs = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char*>(vol) + (lay.offset[0] * (int64_t)sizeof(T) + (int64_t)row * s0.bytes), 0, (int)s0.bytes,
+        0x00020000);
+    s2.nb = (uint32_t)nb2;
+    s2.kb = (uint32_t)(lay.bias[L > 2 ? 2 : 0] - RC_WRAP_ROWS / 8);
+    s2.bytes = (uint32_t)nb2 * blk_bytes;
+    s2.rs = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char*>(vol) + (lay.offset[L > 2 ? 2 : 0] * (int64_t)sizeof(T) + (int64_t)row * s2.bytes), 0,
+        (int)s2.bytes, 0x00020000);
+  }
+  const uint32_t oa0 = frag_off(32 * rh), oa1 = frag_off(32 * rh + 16);
+  const bool three = L >= 3;  // store instructions per chunk of an active wave: 3 or 2
+
+  // The two waves that share a SIMD (w and w + 4: the row halves of one column group) run the same program between
+  // the same barriers; left alone they multiply together and convert together, and the matrix pipe idles through
+  // every epilogue.  Waves 4-7 therefore run half a chunk behind: they keep a chunk's sums across the barrier and
+  // write them out while their partner multiplies the next chunk, then multiply while the partner writes out
+  // (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).  Nothing else is live across the barrier in this kernel,
+  // so the deferral costs no registers.  MEASURED (profiles/r03/lab_build_stagger.txt): no gain here -- the late
+  // wave's epilogue, beside its partner's MFMAs, takes as much longer (1 400 -> 2 800 cycles) as its MFMA phase gets
+  // shorter (2 050 -> 950): the chunk takes 3 900 cycles either way, so the stagger is left switched off.
+#ifndef RC_BUILD_STAGGER
+#define RC_BUILD_STAGGER 0
+#endif
+  const bool late = RC_BUILD_STAGGER && rh != 0;
+  f4v acc[2][2];
+  auto multiply = [&](int c) {
+    const unsigned char* cur = smem + (c & 1) * G_BUF;
+#pragma unroll
+    for (int kb = 0; kb < C::NKS; ++kb) {
+      const s8v a0 = tr_frag_g(cur, oa0, kb), a1 = tr_frag_g(cur, oa1, kb);
+      if (kb == 0) {
+        acc[0][0] = mfma16<T>(a0, bfrag[0][0], (f4v)(0.f));
+        acc[0][1] = mfma16<T>(a0, bfrag[0][1], (f4v)(0.f));
+        acc[1][0] = mfma16<T>(a1, bfrag[0][0], (f4v)(0.f));
+        acc[1][1] = mfma16<T>(a1, bfrag[0][1], (f4v)(0.f));
+      } else {
+        acc[0][0] = mfma16<T>(a0, bfrag[kb][0], acc[0][0]);
+        acc[0][1] = mfma16<T>(a0, bfrag[kb][1], acc[0][1]);
+        acc[1][0] = mfma16<T>(a1, bfrag[kb][0], acc[1][0]);
+        acc[1][1] = mfma16<T>(a1, bfrag[kb][1], acc[1][1]);
+      }
+    }
+  };
+  for (int c = 0; c < n_chunks; ++c) {
+    // chunk c >= 1 has landed once all but the vector-memory operations issued after its DMA are done: the stores
+    // of the epilogue that followed it (none yet for a late wave at c = 1, none ever for an inactive wave)
+    if (c == 0) {  // chunk 0 came through registers: this wave's LDS stores of it must have landed
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else if (!active || (late && c == 1)) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (three) {
+      asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();  // everybody's share of chunk c is in LDS; everybody is done reading chunk c - 1
+    RC_STAMP(6 + 4 * c);
+    if (c >= 1 && c + 1 < n_chunks) dma_tile<T>(f2row, ks2, W2, (c + 1) * C::TN, lds0 + ((c + 1) & 1) * G_BUF, wave);
+    if (active) {
+      if (late) {
+        if (c >= 1) epilogue16_g<T>(acc, scale, s0, s2, blk_bytes, W1, L, (c - 1) * C::TN + 32 * rh, cw);
+        RC_STAMP(7 + 4 * c);
+        multiply(c);
+      } else {
+        multiply(c);
+        RC_STAMP(7 + 4 * c);
+        epilogue16_g<T>(acc, scale, s0, s2, blk_bytes, W1, L, c * C::TN + 32 * rh, cw);
+      }
+      RC_STAMP(9 + 4 * c);
+    }
+  }
+  if (active && late) epilogue16_g<T>(acc, scale, s0, s2, blk_bytes, W1, L, (n_chunks - 1) * C::TN + 32 * rh, cw);
 }
 
 template <typename T, typename VT, int FAST>
@@ -667,6 +976,9 @@ int launch_build(const void* f1, const void* f2, void* vol, const rc_layout* lay
       if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&build16_kernel<T, 2>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * C::LDS_BYTES);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&build16g_kernel<T>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G_BUF);
     }
     if (e != hipSuccess) {
       rc_set_error("hipFuncSetAttribute(%d bytes LDS): %s", C::LDS_BYTES, hipGetErrorString(e));
@@ -693,7 +1005,15 @@ int launch_build(const void* f1, const void* f2, void* vol, const rc_layout* lay
   hipLaunchKernelGGL((build16_kernel<T, F>), dim3((unsigned)blocks), dim3(BT16), 2 * C::LDS_BYTES, st, (const T*)f1, \
                      (const T*)f2, (T*)vol, d, D, scale, n_tiles, n_rows)
   if constexpr (C::IS16 && std::is_same<T, VT>::value) {
-    if (fast && whole) RC_LAUNCH_BUILD16(2);
+    // rows of whole, 16-byte aligned segments and levels wide enough for the branch-free block-row arithmetic:
+    // the LDS-DMA kernel
+    bool dma = fast && whole && lay->W1 % 8 == 0 && lay->W2 % 8 == 0 && ((uintptr_t)f1) % 16 == 0 &&
+               ((uintptr_t)f2) % 16 == 0 && !getenv("RC_BUILD_NO_DMA");
+    for (int i = 0; i < lay->L; i += 2) dma = dma && d.bias[i] <= 3 * (lay->widthp[i] / 8);
+    if (dma)
+      hipLaunchKernelGGL((build16g_kernel<T>), dim3((unsigned)blocks), dim3(BT16), 2 * G_BUF, st, (const T*)f1,
+                         (const T*)f2, (T*)vol, d, scale, n_tiles, n_rows);
+    else if (fast && whole) RC_LAUNCH_BUILD16(2);
     else if (fast) RC_LAUNCH_BUILD16(1);
     else RC_LAUNCH_BUILD16(0);
   } else {

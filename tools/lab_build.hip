@@ -21,6 +21,10 @@
     }                                                                              \
   } while (0)
 
+#ifdef RC_LAB_STAMPS
+extern "C" int rc_lab_read_stamps(unsigned long long*, size_t);
+#endif
+
 int main(int argc, char** argv) {
   const int B = argc > 1 ? atoi(argv[1]) : 8;
   const int H = 96, W = argc > 2 ? atoi(argv[2]) : 312, D = 256, L = 4;
@@ -38,26 +42,65 @@ int main(int argc, char** argv) {
   std::reverse(hf.begin(), hf.end());
   CK(hipMemcpy(f2, hf.data(), fe * 2, hipMemcpyHostToDevice));
   const int N = 30;
-  std::vector<hipEvent_t> ev(N + 1);
+  // RC_LAB_COLD=1: a 1 GiB fill between the launches, so that every build finds the caches as it does inside a
+  // step (its inputs were produced long ago, 32 lookups ran in between), not as the previous build left them
+  const bool cold = getenv("RC_LAB_COLD") != nullptr;
+  void* flush = nullptr;
+  if (cold) CK(hipMalloc(&flush, (size_t)1 << 30));
+  std::vector<hipEvent_t> ev(2 * N + 2);
   for (auto& e : ev) CK(hipEventCreate(&e));
   for (int i = 0; i < 3; ++i)
     if (rc_build_pyramid(f1, f2, vol, &lay, D, RC_F16, 0)) { fprintf(stderr, "%s\n", rc_last_error_string()); return 1; }
   CK(hipDeviceSynchronize());
-  CK(hipEventRecord(ev[0], 0));
   for (int i = 0; i < N; ++i) {
+    if (cold) CK(hipMemsetAsync(flush, i, (size_t)1 << 30, 0));
+    CK(hipEventRecord(ev[2 * i], 0));
     rc_build_pyramid(f1, f2, vol, &lay, D, RC_F16, 0);
-    CK(hipEventRecord(ev[i + 1], 0));
+    CK(hipEventRecord(ev[2 * i + 1], 0));
   }
-  CK(hipEventSynchronize(ev[N]));
+  CK(hipEventSynchronize(ev[2 * N - 1]));
   std::vector<float> us(N);
   for (int i = 0; i < N; ++i) {
     float ms;
-    CK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+    CK(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
     us[i] = ms * 1e3f;
   }
   std::sort(us.begin(), us.end());
-  const double alg = 2.0 * fe * 2 + (double)B * H * W * W * 2 * 1.875, flop = 2.0 * B * H * (double)W * W * D;
-  printf("ablate=%d B=%d W=%d: min %.1f med %.1f max %.1f us   %.1f GB/s alg, %.1f TFLOP/s (median)\n", RC_LAB_ABLATE, B, W,
+  const double alg = 2.0 * fe * 2 + (double)B * H * W * W * 2 * 1.25, flop = 2.0 * B * H * (double)W * W * D;
+  printf("%sablate=%d B=%d W=%d: min %.1f med %.1f max %.1f us   %.1f GB/s alg, %.1f TFLOP/s (median)\n", cold ? "cold " : "", RC_LAB_ABLATE, B, W,
          us[0], us[N / 2], us[N - 1], alg / us[N / 2] / 1e3, flop / us[N / 2] / 1e6);
+#ifdef RC_LAB_STAMPS
+  {
+    // phase durations (shader cycles) of the last launch, per wave: median over the workgroups' waves 0 and 7
+    const int NS = 32, n_wg = std::min(4096, (B * H + 7) / 8 * 8 * ((W + 127) / 128));
+    std::vector<unsigned long long> st((size_t)4096 * 8 * NS);
+    if (rc_lab_read_stamps(st.data(), st.size())) return 1;
+    const int n_chunks = (W + 63) / 64;
+    auto med = [&](int a, int b, int wave) {
+      std::vector<double> d;
+      for (int g = 0; g < n_wg; ++g) {
+        const unsigned long long* p = &st[((size_t)g * 8 + wave) * NS];
+        if (p[a] && p[b] && p[b] >= p[a]) d.push_back((double)(p[b] - p[a]));
+      }
+      if (d.empty()) return -1.0;
+      std::sort(d.begin(), d.end());
+      return d[d.size() / 2];
+    };
+    // every stamped slot in order; the median time from the previous stamped slot is printed under the slot's number
+    // (slot meanings: see the RC_STAMP calls of the kernel that ran: build16_kernel or build16g_kernel in build.hip)
+    for (int wave : {0, 3, 4, 7}) {
+      printf("wave %d, cycles from the previous stamp (median over %d workgroups):", wave, n_wg);
+      int prev = -1;
+      for (int sl = 0; sl < NS; ++sl) {
+        bool any = false;
+        for (int g = 0; g < n_wg && !any; ++g) any = st[((size_t)g * 8 + wave) * NS + sl] != 0;
+        if (!any) continue;
+        if (prev >= 0) printf("  [%d] %.0f", sl, med(prev, sl, wave));
+        prev = sl;
+      }
+      printf("   | lifetime %.0f\n", med(0, prev, wave));
+    }
+  }
+#endif
   return 0;
 }
