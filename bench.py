@@ -704,6 +704,36 @@ def refine_train_step(step, cfg, device, reps=2, dist=None):
     return out
 
 
+def reg_hip_beside_alt(step, cfg, device, n=20):
+    """Beside an alt workload: the same lookups from a MATERIALISED pyramid (reg_hip) of the same feature maps.
+    The reference offers alt to save memory on large frames (README: 'significantly decrease memory consumption ...
+    slower'); on a 288 GB part the Middlebury-F pyramid is 0.7 GB, so a caller should see what not materialising
+    costs per lookup here, and what the build costs once per pair."""
+    import raft_stereo_amd as R
+    with torch.no_grad():
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        blk = R.CorrBlock1DHip(step.f1, step.f2, num_levels=LEVELS, radius=RADIUS)
+        torch.cuda.synchronize()
+        a.record()
+        blk = R.CorrBlock1DHip(step.f1, step.f2, num_levels=LEVELS, radius=RADIUS)
+        b.record()
+        b.synchronize()
+        build_us = a.elapsed_time(b) * 1e3
+        for c in step.coords_list[:3]:
+            blk(c)
+        a.record()
+        for k in range(n):
+            blk(step.coords_list[k % len(step.coords_list)])
+        b.record()
+        b.synchronize()
+        us = a.elapsed_time(b) / n * 1e3
+        agree = float((blk(step.coords_list[0]) - step.cls(step.f1, step.f2, num_levels=LEVELS, radius=RADIUS)(
+            step.coords_list[0])).abs().max())
+    return dict(reg_hip_at_this_size_us=round(us, 2), reg_hip_build_at_this_size_us=round(build_us, 1),
+                reg_hip_pyramid_gb=round(blk.volume.numel() * blk.volume.element_size() / 1e9, 3),
+                reg_hip_vs_alt_max_abs_diff=round(agree, 5))
+
+
 def hbm_resident_lookup(cfg, device, seed, batch=64, passes=3):
     """The lookup's roofline once more at a batch whose touched pyramid lines and outputs no longer fit
     the 256 MiB Infinity Cache (64 KITTI pairs: what one pass reads and writes is ~0.5 GB), beside the
@@ -924,6 +954,8 @@ def main():
                      build_traffic=build_tr[0], build_traffic_source=build_tr[1])
     else:
         extra.update(prepare_ms=round(build_ms, 4))
+        if world == 1 and not args.loop_only:
+            extra.update(reg_hip_beside_alt(step, cfg, device))       # side leg, after the timed region
     if cfg["train"]:
         extra.update(backward_ms=round(float(np.median(step.bwd_ms)), 4))
 

@@ -399,7 +399,10 @@ __global__ __launch_bounds__(RC_MAX_LEVELS * TP) void adjoint_dense_kernel(adj_l
     for (int k = 0; k < NT; ++k) voff[k] = (uint32_t)(lvl * NT + k) * (uint32_t)HW + (uint32_t)p;
     // PD lookups' planes are in flight at any time: with the pixel tile bounded by LDS only a few
     // waves fit on a CU, so the latency has to be covered from inside the wave
-    constexpr int PD = 4;
+#ifndef RC_LAB_ADJ_PD
+#define RC_LAB_ADJ_PD 4
+#endif
+    constexpr int PD = RC_LAB_ADJ_PD;
     float xs[PD], gs[PD][NT];
     auto fetch = [&](int t, int slot) {  // t is block-uniform: the list entries come through scalar loads
       xs[slot] = (((rc_gptr)lists.coords[t]) + cu)[(uint32_t)p];
