@@ -21,6 +21,16 @@
     }                                                                              \
   } while (0)
 
+// reads `n` 16-byte pieces and keeps nothing: empties the caches of the build's data without leaving dirty lines
+__global__ void lab_sweep(const uint4* __restrict__ p, size_t n, uint32_t* sink) {
+  uint32_t acc = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const uint4 v = p[i];
+    acc += v.x ^ v.y ^ v.z ^ v.w;
+  }
+  if (acc == 0x12345678u) *sink = acc;
+}
+
 #ifdef RC_LAB_STAMPS
 extern "C" int rc_lab_read_stamps(unsigned long long*, size_t);
 #endif
@@ -44,16 +54,21 @@ int main(int argc, char** argv) {
   const int N = 30;
   // RC_LAB_COLD=1: a 1 GiB fill between the launches, so that every build finds the caches as it does inside a
   // step (its inputs were produced long ago, 32 lookups ran in between), not as the previous build left them
-  const bool cold = getenv("RC_LAB_COLD") != nullptr;
+  // RC_LAB_COLD=2: a read-only sweep of 1 GiB instead (cold caches, no dirty lines: what a build finds inside a step)
+  const int cold = getenv("RC_LAB_COLD") ? atoi(getenv("RC_LAB_COLD")) : 0;
   void* flush = nullptr;
-  if (cold) CK(hipMalloc(&flush, (size_t)1 << 30));
+  if (cold) {
+    CK(hipMalloc(&flush, ((size_t)1 << 30) + 64));
+    CK(hipMemset(flush, 1, ((size_t)1 << 30) + 64));
+  }
   std::vector<hipEvent_t> ev(2 * N + 2);
   for (auto& e : ev) CK(hipEventCreate(&e));
   for (int i = 0; i < 3; ++i)
     if (rc_build_pyramid(f1, f2, vol, &lay, D, RC_F16, 0)) { fprintf(stderr, "%s\n", rc_last_error_string()); return 1; }
   CK(hipDeviceSynchronize());
   for (int i = 0; i < N; ++i) {
-    if (cold) CK(hipMemsetAsync(flush, i, (size_t)1 << 30, 0));
+    if (cold == 1) CK(hipMemsetAsync(flush, i, (size_t)1 << 30, 0));
+    if (cold == 2) lab_sweep<<<2048, 256>>>((const uint4*)flush, ((size_t)1 << 30) / 16, (uint32_t*)((char*)flush + ((size_t)1 << 30)));
     CK(hipEventRecord(ev[2 * i], 0));
     rc_build_pyramid(f1, f2, vol, &lay, D, RC_F16, 0);
     CK(hipEventRecord(ev[2 * i + 1], 0));
@@ -67,7 +82,7 @@ int main(int argc, char** argv) {
   }
   std::sort(us.begin(), us.end());
   const double alg = 2.0 * fe * 2 + (double)B * H * W * W * 2 * 1.25, flop = 2.0 * B * H * (double)W * W * D;
-  printf("%sablate=%d B=%d W=%d: min %.1f med %.1f max %.1f us   %.1f GB/s alg, %.1f TFLOP/s (median)\n", cold ? "cold " : "", RC_LAB_ABLATE, B, W,
+  printf("%sablate=%d B=%d W=%d: min %.1f med %.1f max %.1f us   %.1f GB/s alg, %.1f TFLOP/s (median)\n", cold == 1 ? "cold+dirty " : cold == 2 ? "cold " : "", RC_LAB_ABLATE, B, W,
          us[0], us[N / 2], us[N - 1], alg / us[N / 2] / 1e3, flop / us[N / 2] / 1e6);
 #ifdef RC_LAB_STAMPS
   {
