@@ -695,6 +695,11 @@ __global__ __launch_bounds__(BT16, 4) void build16g_kernel(const T* __restrict__
   f4v acc[2][2];
   auto multiply = [&](int c) {
     const unsigned char* cur = smem + (c & 1) * G_BUF;
+    if constexpr (RC_LAB_ABLATE & 2) {  // lab: no LDS reads, no MFMA
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e >> 1][e & 1] = (f4v)((float)cur[threadIdx.x + e] + (float)bfrag[e][0][0]);
+      return;
+    }
 #pragma unroll
     for (int kb = 0; kb < C::NKS; ++kb) {
       const s8v a0 = tr_frag_g(cur, oa0, kb), a1 = tr_frag_g(cur, oa1, kb);
