@@ -943,8 +943,10 @@ def main():
         hbm_cap_tf = cnt["build_flops"] / cnt["build_bytes"] * HBM_PEAK_GBS / 1e3
         hbm_cap_survey = cnt["build_flops"] / cnt["build_bytes_survey_count"] * HBM_PEAK_GBS / 1e3
         build_gbps = cnt["build_bytes"] / (build_ms * 1e-3) / 1e9
-        build_tr = measured_traffic(args.workload, cfg["batch"], "build16_kernel" if cfg["dtype"] != "f32" else "build_kernel") \
-            if stock else (None, None)
+        build_tr = (None, None)
+        for kname in (["build_kernel"] if cfg["dtype"] == "f32" else ["build16g_kernel", "build16_kernel"]):
+            if stock and build_tr[0] is None:        # (the LDS-DMA kernel where the shape is eligible, else round 2's)
+                build_tr = measured_traffic(args.workload, cfg["batch"], kname)
         extra.update(build_tflops=round(tf, 2), build_ms=round(build_ms, 4), build_frac_mfma=round(tf / peak, 4),
                      build_gbps=round(build_gbps, 1), build_algorithmic_bytes=int(cnt["build_bytes"]),
                      build_frac_of_binding_roof=round(tf / min(peak, hbm_cap_tf), 4),
