@@ -992,7 +992,7 @@ def main():
     if profiler:
         extra["profiler_attached"] = True
     if (args.workload == "kitti" and not args.batch and not args.dtype and world == 1 and not args.loop_only
-            and not args.profile):
+            and not args.profile and not args.adversarial):
         # the same kernel with nothing left in the Infinity Cache between lookups (after the timed region)
         extra["roofline_hbm_resident"] = hbm_resident_lookup(cfg, device, 1234 + rank)
         extra["lookup_frac_hbm_resident"] = extra["roofline_hbm_resident"]["frac"]
