@@ -196,6 +196,30 @@ def test_build_mfma_equals_naive_kernel(R, dtype, shape):
         assert torch.equal(a, b), f"level {i} differs: max {float((a - b).abs().max())}"
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape,scale", [((2, 256, 5, 312, 312), 1.0), ((1, 256, 3, 136, 200), 1.0),
+                                         ((1, 256, 4, 312, 312), 2e-3), ((1, 256, 2, 180, 180), 2e-3),
+                                         ((1, 256, 3, 80, 752), 30.0)])
+def test_stored_level2_is_the_twice_pooled_stored_level0(R, dtype, shape, scale):
+    """On real-valued data the MFMA build cannot be compared with the naive kernel bit for bit (the fp32 sums are
+    added in another order), but its pooling can be checked exactly against its OWN level 0: level 2 must be
+    avg_pool2d's arithmetic applied twice -- the fp32 mean of two stored values, rounded once to the storage type
+    (core/corr.py:42 on a 16-bit volume) -- whichever instructions the epilogue uses for it (round 3: mixed-precision
+    FMAs for fp16).  The small scale puts values into fp16's subnormal range, the large one near its top."""
+    B, D, H, W1, W2 = shape
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    f1 = (torch.randn((B, D, H, W1), generator=gen, device="cuda") * scale).to(dtype)
+    f2 = (torch.randn((B, D, H, W2), generator=gen, device="cuda") * scale).to(dtype)
+    blk = R.CorrBlock1DHip(f1, f2, num_levels=4, radius=4)
+    lvl = blk.dense_level(0)
+    assert torch.isfinite(lvl.float()).all()
+    for i in (1, 2):
+        n = lvl.shape[-1] // 2
+        lvl = ((lvl[..., 0:2 * n:2].float() + lvl[..., 1:2 * n:2].float()) * 0.5).to(dtype)
+    got = blk.dense_level(2)
+    assert torch.equal(got, lvl), f"{int((got != lvl).sum())} of {lvl.numel()} level-2 entries differ"
+
+
 # ------------------------------------------------------------------ 16-bit against the rounded-input oracle
 def _round(a, dtype):
     return torch.from_numpy(a).to(dtype).float().numpy()
