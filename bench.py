@@ -178,9 +178,15 @@ class Step:
         if self.train:
             self.f1.requires_grad_(True)
             self.f2.requires_grad_(True)
+            # one gradient tensor PER LOOKUP, as training has (each iteration's loss term reaches its own lookup):
+            # rounds 1-2 and the first r03 profiles passed one tensor to all of them, which then sat in the
+            # caches while the fused adjoint read it 22 times (68 us); with 22 tensors (365 MB at config 3,
+            # more than the Infinity Cache) the same kernel takes 108 us
             g = torch.Generator(device=device).manual_seed(seed + 1)
-            self.gout = torch.randn((cfg["batch"], LEVELS * (2 * RADIUS + 1), cfg["H"], cfg["W"]), generator=g,
-                                    device=device)
+            self.gouts = [torch.randn((cfg["batch"], LEVELS * (2 * RADIUS + 1), cfg["H"], cfg["W"]), generator=g,
+                                      device=device) for _ in range(cfg["iters"])]
+            if os.environ.get("RC_BENCH_SHARED_GOUT"):      # lab: the old behaviour, to compare with old profiles
+                self.gouts = [self.gouts[0]] * cfg["iters"]
         self.cls = R.CORR_IMPLEMENTATIONS[cfg["impl"]][0]
         self.events = []          # one set of 4 HIP events per recorded step (torch's current stream
         self.build_ms, self.lookup_ms, self.bwd_ms = [], [], []   # is the stream the kernels run on)
@@ -203,7 +209,7 @@ class Step:
             self.ev[2].record()
         if self.train:
             self.f1.grad = self.f2.grad = None
-            torch.autograd.backward(outs, [self.gout] * len(outs))
+            torch.autograd.backward(outs, self.gouts)
         if record:
             self.ev[3].record()
         return out

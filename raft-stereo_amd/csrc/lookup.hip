@@ -282,12 +282,21 @@ __global__ __launch_bounds__(LK_THREADS) void lookup_bwd_kernel(const float* __r
 
 // One lookup's contribution to one (level, pixel) gradient row held in LDS: the 2r+1 tap gradients g
 // spread over the window entries around xi (the level's coordinate).  The row belongs to the calling
-// thread alone; cell row[Wi] is a sink for entries outside the image.
+// thread alone; its cells are S floats apart (the rows of a workgroup's S pixels are interleaved, so lane
+// p is always in bank p whatever its window), and it has ADJ_PAD cells on either side of the image's Wi:
+// cell w2 is row[(w2 + PAD) * S].  A window that touches the image at all lies inside the padded row, so
+// every lookup is the same ten-odd read-add-writes at constant offsets from one address: no per-entry
+// clamp, no second code path for windows at the image's edge (at the coarse levels most windows are).
 template <int R, int MODE>
+struct adj_pad {
+  static constexpr int value = win_info<4, R, MODE>::NW - 1;
+};
+
+template <int R, int MODE, int S>
 __device__ __forceinline__ void adjoint_accumulate(float* row, int Wi, float xi, float wm1,
                                                    const float (&g)[2 * R + 1]) {
   using WI = win_info<4, R, MODE>;
-  constexpr int NT = WI::NT, EXT = WI::EXT, NW = WI::NW;
+  constexpr int NT = WI::NT, EXT = WI::EXT, NW = WI::NW, PAD = adj_pad<R, MODE>::value;
   const float xf = floorf(xi);
   const float a = xi - xf;
   const int wbase = rc_safe_int(xf) - R - EXT;
@@ -319,25 +328,11 @@ __device__ __forceinline__ void adjoint_accumulate(float* row, int Wi, float xi,
     }
   }
   float cur[NW];
-  if (!__any(wbase < 0 || wbase + NW > Wi)) {
-    // every window of the wave lies inside the image: one base address, constant offsets
-    float* win = row + wbase;
+  float* win = row + (wbase + PAD) * S;
 #pragma unroll
-    for (int m = 0; m < NW; ++m) cur[m] = win[m];
+  for (int m = 0; m < NW; ++m) cur[m] = win[m * S];
 #pragma unroll
-    for (int m = 0; m < NW; ++m) win[m] = cur[m] + tw[m];
-    return;
-  }
-  // branch-free: entries outside the image add their (unused) value to the sink cell row[Wi]
-  int idx[NW];
-#pragma unroll
-  for (int m = 0; m < NW; ++m) {
-    const int w2 = wbase + m;
-    idx[m] = (unsigned)w2 < (unsigned)Wi ? w2 : Wi;
-    cur[m] = row[idx[m]];
-  }
-#pragma unroll
-  for (int m = 0; m < NW; ++m) row[idx[m]] = cur[m] + tw[m];
+  for (int m = 0; m < NW; ++m) win[m * S] = cur[m] + tw[m];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -350,6 +345,24 @@ __device__ __forceinline__ void adjoint_accumulate(float* row, int Wi, float xi,
 // lookups, adds each one's 2r+2 window entries into its row with plain LDS read-add-write (no
 // atomics: nobody else touches the row; the next lookup's gradient planes are in flight
 // meanwhile), then all threads fold the levels and write each dense row once.
+#ifdef RC_LAB_ADJ_STAMPS  // lab: s_memtime per wave at the kernel's phases (tools/lab_adj_stamps.py)
+}  // namespace
+constexpr int RC_ADJ_NSTAMP = 16;
+__device__ unsigned long long rc_lab_adj_stamps[8192 * 4 * RC_ADJ_NSTAMP];
+extern "C" int rc_lab_adj_read_stamps(unsigned long long* dst, size_t n) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(rc_lab_adj_stamps), n * sizeof(unsigned long long));
+}
+namespace {
+#define RC_ASTAMP(slot)                                                                      \
+  do {                                                                                       \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 8192 && (slot) < RC_ADJ_NSTAMP)              \
+      rc_lab_adj_stamps[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RC_ADJ_NSTAMP + (slot)] = \
+          __builtin_amdgcn_s_memtime();                                                      \
+  } while (0)
+#else
+#define RC_ASTAMP(slot) do {} while (0)
+#endif
+
 struct adj_lists {
   const float* coords[RC_MAX_FUSED_LOOKUPS];
   const float* gout[RC_MAX_FUSED_LOOKUPS];
@@ -358,8 +371,7 @@ struct adj_lists {
 struct adj_dims {
   int B, H, W1, W2, L, ldc, n, cc;
   int width[RC_MAX_LEVELS];
-  int pitch[RC_MAX_LEVELS];  // LDS row pitch of level i (floats): odd and > width (cell `width` is a sink)
-  int base[RC_MAX_LEVELS];   // LDS offset of level i = TP * sum of the lower pitches
+  int base[RC_MAX_LEVELS];  // LDS offset of level i (floats) = TP * sum over the lower levels of (width + 2 * PAD)
 };
 
 typedef const float __attribute__((address_space(1)))* rc_gptr;  // a pointer known to be global memory
@@ -372,81 +384,144 @@ __global__ __launch_bounds__(RC_MAX_LEVELS * TP) void adjoint_dense_kernel(adj_l
   constexpr int NTHR = RC_MAX_LEVELS * TP;
   extern __shared__ __attribute__((aligned(16))) float acc[];
 
+  // Workgroups go to the 8 XCDs round-robin: each XCD takes a contiguous eighth of the (row, tile) list, so the
+  // tiles of an image row, whose 128-byte pieces of a plane share lines (a row is not a whole number of
+  // lines), meet in one L2, and what an XCD asks of memory is runs of neighbouring rows.  Reading this input
+  // alone: 3.7 TB/s in plain order, 5.2 TB/s in this one (tools/lab_adj_pattern.hip).
   const int tiles = (d.W1 + TP - 1) / TP;
-  const int bh = blockIdx.x / tiles;
-  const int c0 = (blockIdx.x - bh * tiles) * TP;
+  const int n_tiles = d.B * d.H * tiles;
+#ifdef RC_LAB_ADJ_PLAIN_ORDER
+  const int id = blockIdx.x;
+#else
+  const int id = (int)(blockIdx.x & 7) * ((n_tiles + 7) >> 3) + (int)(blockIdx.x >> 3);
+#endif
+  if (id >= n_tiles) return;
+  const int bh = id / tiles;
+  const int c0 = (id - bh * tiles) * TP;
   const int b = bh / d.H, h = bh - b * d.H;
   const int p = threadIdx.x % TP, lvl = threadIdx.x / TP;
   const int w1 = c0 + p;
   const int64_t HW = (int64_t)d.H * d.W1;
   const int L = d.L;
-  const int total = d.base[L - 1] + TP * d.pitch[L - 1];  // floats of LDS in use
+  constexpr int PAD = adj_pad<R, MODE>::value;
+  const int total = d.base[L - 1] + TP * (d.width[L - 1] + 2 * PAD);  // floats of LDS in use
 
-  typedef float f4z __attribute__((ext_vector_type(4)));
-  for (int e = threadIdx.x; e < (total + 3) >> 2; e += NTHR) reinterpret_cast<f4z*>(acc)[e] = (f4z){0.f, 0.f, 0.f, 0.f};
-  __syncthreads();
-
-  if (w1 < d.W1 && lvl < L) {
-    const int Wi = d.width[lvl];
-    const float inv = 1.0f / (float)(1 << lvl);
-    const float wm1 = (float)(Wi - 1);
-    float* row = acc + d.base[lvl] + p * d.pitch[lvl];
-    // wave-uniform bases + 32-bit lane offsets (computed once): a fetch costs no address arithmetic
-    const int64_t cu = uniform(((int64_t)b * d.cc) * HW + (int64_t)h * d.W1 + c0);
-    const int64_t gu = uniform(((int64_t)b * L * NT) * HW + (int64_t)h * d.W1 + c0);
-    uint32_t voff[NT];
+  RC_ASTAMP(0);
+  // selects, not d.width[lvl]: indexing the kernel argument by a lane's level is a vector memory load, and the
+  // compiler then waits for ALL loads in flight wherever the loop below reads the value
+  // (the empty asm keeps the compiler from turning the selects back into that load)
+  auto of_level = [&](const int (&a)[RC_MAX_LEVELS]) {
+    int v = 0;
 #pragma unroll
-    for (int k = 0; k < NT; ++k) voff[k] = (uint32_t)(lvl * NT + k) * (uint32_t)HW + (uint32_t)p;
-    // PD lookups' planes are in flight at any time: with the pixel tile bounded by LDS only a few
-    // waves fit on a CU, so the latency has to be covered from inside the wave
+    for (int i = 0; i < RC_MAX_LEVELS; ++i) {
+      int ai = a[i];
+      asm volatile("" : "+s"(ai));
+      v = lvl == i ? ai : v;
+    }
+    return v;
+  };
+  const bool active = w1 < d.W1 && lvl < L;
+  const int Wi = of_level(d.width);
+  const float inv = 1.0f / (float)(1 << lvl);
+  const float wm1 = (float)(Wi - 1);
+  float* row = acc + of_level(d.base) + p;  // cell w2 of this thread's row is row[(w2 + PAD) * TP]
+  // wave-uniform bases + 32-bit lane offsets (computed once): a fetch costs no address arithmetic
+  const int64_t cu = uniform(((int64_t)b * d.cc) * HW + (int64_t)h * d.W1 + c0);
+  const int64_t gu = uniform(((int64_t)b * L * NT) * HW + (int64_t)h * d.W1 + c0);
+  uint32_t voff[NT];  // in bytes (< 2^31, checked by the caller): uniform base + 32-bit lane offset is one instruction
+#pragma unroll
+  for (int k = 0; k < NT; ++k) voff[k] = ((uint32_t)(lvl * NT + k) * (uint32_t)HW + (uint32_t)p) * 4u;
+  // PD lookups' planes are in flight at any time: with the pixel tile bounded by LDS only a few
+  // waves fit on a CU, so the latency has to be covered from inside the wave
 #ifndef RC_LAB_ADJ_PD
 #define RC_LAB_ADJ_PD 4
 #endif
-    constexpr int PD = RC_LAB_ADJ_PD;
-    float xs[PD], gs[PD][NT];
-    auto fetch = [&](int t, int slot) {  // t is block-uniform: the list entries come through scalar loads
-      xs[slot] = (((rc_gptr)lists.coords[t]) + cu)[(uint32_t)p];
-      rc_gptr gp = ((rc_gptr)lists.gout[t]) + gu;
+#ifndef RC_LAB_ADJ_ABLATE
+#define RC_LAB_ADJ_ABLATE 0
+#endif
+  constexpr int PD = RC_LAB_ADJ_PD;
+  float xs[PD], gs[PD][NT];
+  // buffer loads: descriptor from the uniform base (scalar work), the lane's precomputed byte offset as it is -- a
+  // global load would spend a 64-bit vector add per plane on the address.  Every fetch is unconditional (a load
+  // under a branch would make the compiler wait for all loads at every join); past the last lookup the
+  // descriptor's size is 0, so the loads touch no memory and return at once.
+  const int last = d.n - 1;
+  auto fetch = [&](int t, int slot) {  // t is block-uniform: the list entries come through scalar loads
+    const int size = t <= last ? 0x7fffffff : 0;
+    const int tc = min(t, last);
+    const __amdgpu_buffer_rsrc_t rc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(lists.coords[tc] + cu), 0, size, 0x00020000);
+    xs[slot] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc, (int)((uint32_t)p * 4u), 0, 0));
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(lists.gout[tc] + gu), 0, size, 0x00020000);
 #pragma unroll
-      for (int k = 0; k < NT; ++k) gs[slot][k] = gp[voff[k]];
-    };
-    // every fetch is unconditional (past the end it re-reads the last lookup, a cache hit): a load
-    // under a branch would make the compiler wait for all loads at every join
-    const int last = d.n - 1;
+    for (int k = 0; k < NT; ++k)
+      gs[slot][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff[k], 0, 0));
+  };
+  float lab_sum = 0.f;
+  // the first PD lookups are asked for before the rows are cleared: their latency passes behind the clearing
+  if (active) {
 #pragma unroll
-    for (int j = 0; j < PD; ++j) fetch(min(j, last), j);
+    for (int j = 0; j < PD; ++j) {  // in the loop's order (slot by slot), or the loop's first wait has to be for everything
+      fetch(j, j);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  typedef float f4z __attribute__((ext_vector_type(4)));
+  for (int e = threadIdx.x; e < (total + 3) >> 2; e += NTHR) reinterpret_cast<f4z*>(acc)[e] = (f4z){0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  RC_ASTAMP(1);
+
+  if (active) {
     for (int t0 = 0; t0 < d.n; t0 += PD) {
+      RC_ASTAMP(2 + t0 / PD);
 #pragma unroll
       for (int j = 0; j < PD; ++j) {
         const int t = t0 + j;
-        const float x = xs[j];
-        float g[NT];
-#pragma unroll
-        for (int k = 0; k < NT; ++k) g[k] = gs[j][k];
-        fetch(min(t + PD, last), j);
-        if (t < d.n) adjoint_accumulate<R, MODE>(row, Wi, x * inv, wm1, g);
+        // consume the slot, THEN refill it: issued the other way round, the new planes land in fresh registers
+        // that are copied into the slot's at the end of every pass of the loop, after a wait for all of them
+#if RC_LAB_ADJ_ABLATE & 1  // lab: the loads alone (their sum goes to the sink cell once)
+        for (int k = 0; k < NT; ++k) lab_sum += gs[j][k] + xs[j];
+#else
+        if (t < d.n) adjoint_accumulate<R, MODE, TP>(row, Wi, xs[j] * inv, wm1, gs[j]);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+#if RC_LAB_ADJ_ABLATE & 2  // lab: no loads of the gradient planes
+        xs[j] = (((rc_gptr)lists.coords[min(t + PD, last)]) + cu)[(uint32_t)p];
+#else
+        fetch(t + PD, j);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
+#if RC_LAB_ADJ_ABLATE & 1
+    row[0] = lab_sum;
+#endif
   }
+  RC_ASTAMP(12);
   __syncthreads();
+  RC_ASTAMP(13);
 
   // fold the levels (a pooled cell spreads 2^-i of its gradient over its 2^i children) and write the
   // dense rows, 8 consecutive w2 per thread
   const int segs = d.ldc >> 3;
+#if RC_LAB_ADJ_ABLATE & 4  // lab: no fold, no stores
+  if (scale != 12345.f) return;
+#endif
   for (int e = threadIdx.x; e < TP * segs; e += NTHR) {
-    const int pp = e / segs, w20 = (e - pp * segs) * 8;
+    const int pp = e % TP, w20 = (e / TP) * 8;  // neighbouring lanes: neighbouring pixels (distinct LDS banks)
     if (c0 + pp >= d.W1) continue;
     // 8 + 4 + 2 + 1 independent LDS reads; levels the pyramid does not have come with width 0
     float part[RC_MAX_LEVELS][8];
 #pragma unroll
     for (int i = 0; i < RC_MAX_LEVELS; ++i) {
-      const float* rw = acc + d.base[i] + pp * d.pitch[i];
+      const float* rw = acc + d.base[i] + pp;
       const int wi0 = w20 >> i;
       const float wgt = scale / (float)(1 << i);
 #pragma unroll
       for (int r = 0; r < (8 >> i); ++r) {
         const int wi = wi0 + r;
-        const float val = rw[min(wi, d.width[i])];
+        const float val = rw[(min(wi, d.width[i] - 1) + PAD) * TP];
         part[i][r] = wi < d.width[i] ? wgt * val : 0.f;
       }
     }
@@ -468,16 +543,15 @@ __global__ __launch_bounds__(RC_MAX_LEVELS * TP) void adjoint_dense_kernel(adj_l
       *reinterpret_cast<t8v*>(dst) = __builtin_convertvector(f, t8v);
     }
   }
+  RC_ASTAMP(14);
 }
 
 template <typename T, int R, int MODE>
 int launch_adjoint_dense(const adj_lists& lists, adj_dims d, void* dC, float scale, hipStream_t st) {
   // the largest pixel tile whose per-level rows fit in 80 KiB of LDS
-  int sum_pitch = 0;
-  for (int i = 0; i < d.L; ++i) {
-    d.pitch[i] = (d.width[i] + 1) | 1;
-    sum_pitch += d.pitch[i];
-  }
+  constexpr int PAD = adj_pad<R, MODE>::value;
+  int sum_pitch = 0;  // cells per pixel: every level's row and its padding
+  for (int i = 0; i < d.L; ++i) sum_pitch += d.width[i] + 2 * PAD;
   int tp = 64;
   while (tp > 8 && (int64_t)tp * sum_pitch * 4 > 80 * 1024) tp >>= 1;
   const int64_t lds = ((int64_t)tp * sum_pitch * 4 + 15) & ~(int64_t)15;
@@ -485,9 +559,9 @@ int launch_adjoint_dense(const adj_lists& lists, adj_dims d, void* dC, float sca
   int off = 0;
   for (int i = 0; i < d.L; ++i) {
     d.base[i] = off;
-    off += tp * d.pitch[i];
+    off += tp * (d.width[i] + 2 * PAD);
   }
-  const int64_t blocks = (int64_t)d.B * d.H * ((d.W1 + tp - 1) / tp);
+  const int64_t blocks = ((int64_t)d.B * d.H * ((d.W1 + tp - 1) / tp) + 7) / 8 * 8;  // a whole number per XCD
   RC_REQUIRE(blocks < (1ll << 31), RC_EINVAL, "too many pixels");
 #define RC_ADJ(TPV)                                                                                       \
   case TPV: {                                                                                             \
@@ -715,7 +789,6 @@ extern "C" int rc_lookup_bwd_dense(const float* const* coords_list, const float*
   d.cc = coords_channels;
   for (int i = 0; i < RC_MAX_LEVELS; ++i) {
     d.width[i] = i < glay->L ? glay->width[i] : 0;  // width 0: the fold skips the level
-    d.pitch[i] = 0;
     d.base[i] = 0;
   }
   const float scale = (float)(1.0 / sqrt((double)D));
