@@ -149,6 +149,7 @@ struct fc_update {
   int delta_dtype;     // RC_F32 / RC_F16 / RC_BF16
   float* coords_out;   // [B,2,H,W1]
   float* flow_out;     // [B,2,H,W1]
+  int wgs_per_xcd;     // set by the launcher: > 0 = each XCD takes that many consecutive workgroups' pixels
 };
 
 // TILE: 16-bit outputs made of whole 16-byte pieces (decided by the launcher) leave through the LDS tile
@@ -172,7 +173,14 @@ __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __r
   // (image, 64-pixel chunk), wave-uniform.  A block's chunks are 256 consecutive pixels of ONE image (the
   // launcher counts chunks_per_image in whole blocks): chunks past the end of the image gather its last pixel,
   // store nothing, and still reach the block's barriers
-  const int item = blockIdx.x * (FC_THREADS / 64) + wave;
+  // (a launch that is resident all at once gives each XCD a contiguous eighth of the pixels, as the plain lookup
+  // does: lookup.hip)
+  int wg = blockIdx.x;
+  if (upd.wgs_per_xcd > 0) {
+    wg = (int)(blockIdx.x & 7) * upd.wgs_per_xcd + (int)(blockIdx.x >> 3);
+    if (wg * (FC_THREADS / 64) >= n_items) return;  // the whole workgroup: n_items counts whole workgroups
+  }
+  const int item = wg * (FC_THREADS / 64) + wave;
   if (!TILE && item >= n_items) return;
   const int64_t HW_ = (int64_t)lay.H * lay.W1;
   // the lane's pixel inside the chunk (see the header): rows of the later MFMA land 16 consecutive pixels per lane
@@ -456,7 +464,13 @@ int launch_fused(const void* vol, rc_dev_layout d, const float* coords, int cc, 
   constexpr int WPB = FC_THREADS / 64;
   const int chunks = (d.H * d.W1 + FC_THREADS - 1) / FC_THREADS * WPB;  // whole blocks per image
   const int n_items = (int)((int64_t)d.B * chunks);
-  const int blocks = (n_items + (FC_THREADS / 64) - 1) / (FC_THREADS / 64);
+  int blocks = (n_items + (FC_THREADS / 64) - 1) / (FC_THREADS / 64);
+  fc_update updx = upd;
+  updx.wgs_per_xcd = 0;
+  if (blocks <= 1024) {  // resident all at once (256 CUs x 4 of these workgroups)
+    updx.wgs_per_xcd = (blocks + 7) / 8;
+    blocks = updx.wgs_per_xcd * 8;
+  }
   // outputs that cannot stay in the Infinity Cache until their consumer runs leave through non-temporal stores
   // (the same rule and threshold as the plain lookup, lookup.hip); the LDS-tile path only: its stores cover
   // 512 contiguous bytes
@@ -468,7 +482,7 @@ int launch_fused(const void* vol, rc_dev_layout d, const float* coords, int cc, 
     set_row_bias(d, vt_info<VT>::RB, pair_info<vt_info<VT>::RB, R, MODE>::NW2);                               \
     hipLaunchKernelGGL((lookup_convc1_kernel<VT, R, MODE, TILE>), dim3(blocks), dim3(FC_THREADS), 0, st,       \
                        (const VT*)vol, d, coords, cc, (const VT*)wpack, bias, (VT*)out, chunks, n_items, relu, \
-                       nts, upd);                                                                              \
+                       nts, updx);                                                                             \
   } while (0)
   if constexpr (IS16) {
     if (tile) {
