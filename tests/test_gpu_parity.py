@@ -741,6 +741,33 @@ def test_lookup_convc1_equals_unfused_at_full_size(R, dtype, shape, mode):
     assert rel(act, ref.cpu().numpy()) < tol
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_lookups_are_the_same_in_either_workgroup_order(R, dtype):
+    """A launch of at most 1024 workgroups gives each XCD a contiguous eighth of the pixels, a larger one deals
+    workgroups round-robin (lookup.hip, fused.hip).  12 images at once (1 404 workgroups: plain order) must equal
+    the same images four at a time (468 workgroups, not a multiple of 8: the other order), bit for bit, for the
+    plain lookup, the lookup with the coordinate update and the fused lookup + convc1."""
+    gen = torch.Generator(device="cuda").manual_seed(31)
+    B, D, H, W = 12, 64, 96, 312
+    f1 = torch.randn((B, D, H, W), generator=gen, device="cuda").to(dtype)
+    f2 = torch.randn((B, D, H, W), generator=gen, device="cuda").to(dtype)
+    c = torch.from_numpy(O.synthetic_coords(B, H, W, seed=8)).cuda()
+    delta = torch.randn((B, 2, H, W), generator=gen, device="cuda")
+    wgt = torch.randn((64, 36, 1, 1), generator=gen, device="cuda") * 0.3
+    bias = torch.randn((64,), generator=gen, device="cuda")
+    with torch.no_grad():
+        whole = R.CorrBlock1DHip(f1, f2)
+        out, act = whole(c), whole.lookup_convc1(c, wgt, bias)
+        new, flow, out_u = whole.update_and_lookup(c, delta)
+        for k in range(0, B, 4):
+            sl = slice(k, k + 4)
+            part = R.CorrBlock1DHip(f1[sl].contiguous(), f2[sl].contiguous())
+            assert torch.equal(part(c[sl].contiguous()), out[sl])
+            assert torch.equal(part.lookup_convc1(c[sl].contiguous(), wgt, bias), act[sl])
+            n2, f2_, o2 = part.update_and_lookup(c[sl].contiguous(), delta[sl].contiguous())
+            assert torch.equal(n2, new[sl]) and torch.equal(f2_, flow[sl]) and torch.equal(o2, out_u[sl])
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("levels,radius", [(4, 1), (4, 2), (3, 3), (4, 5), (2, 6), (4, 7), (1, 4)])
 def test_lookup_convc1_tile_path_radii_levels_partial_blocks(R, dtype, levels, radius):

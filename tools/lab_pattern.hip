@@ -31,12 +31,14 @@ __global__ void sweep(const uint4* __restrict__ p, size_t n, uint32_t* sink) {
 
 // One workgroup (WAVES waves) reads the [256 k][CW columns] slice of image row `row` that starts at column c0:
 // CW * 2 bytes per k row, in 128-byte pieces (8 lanes x 16 bytes), 8 k rows per wave instruction.
-template <int CW>
+// ORDER 0: the build's XCD-aware order (XCD x takes the rows = x mod 8); 1: XCD x takes a contiguous eighth of
+// the rows (neighbouring rows, which share a line where one ends and the next begins, meet in one L2)
+template <int CW, int ORDER>
 __global__ __launch_bounds__(512) void read_slices(const uint16_t* __restrict__ f, int H, int W, int n_rows,
                                                    int tiles, uint32_t* sink) {
   const int id = blockIdx.x;
   const int j = id >> 3;
-  const int row = (j / tiles) * 8 + (id & 7);  // the build's XCD-aware order
+  const int row = ORDER == 0 ? (j / tiles) * 8 + (id & 7) : (id & 7) * ((n_rows + 7) / 8) + j / tiles;
   const int tile = j % tiles;
   if (row >= n_rows) return;
   const int b = row / H, h = row - b * H;
@@ -64,7 +66,7 @@ __global__ __launch_bounds__(512) void read_slices(const uint16_t* __restrict__ 
   if (acc == 0x12345678u) sink[threadIdx.x] = acc;
 }
 
-template <int CW>
+template <int CW, int ORDER = 0>
 static double run(const uint16_t* f, int B, int H, int W, const uint4* flush, uint32_t* sink, const char* what) {
   const int n_rows = B * H, tiles = (W + CW - 1) / CW;
   const int blocks = (n_rows + 7) / 8 * 8 * tiles;
@@ -74,7 +76,7 @@ static double run(const uint16_t* f, int B, int H, int W, const uint4* flush, ui
   for (int i = 0; i < N; ++i) {
     sweep<<<2048, 256>>>(flush, ((size_t)1 << 30) / 16, sink);
     CHECK(hipEventRecord(ev[2 * i]));
-    read_slices<CW><<<blocks, 512>>>(f, H, W, n_rows, tiles, sink);
+    read_slices<CW, ORDER><<<blocks, 512>>>(f, H, W, n_rows, tiles, sink);
     CHECK(hipEventRecord(ev[2 * i + 1]));
   }
   CHECK(hipEventSynchronize(ev[2 * N - 1]));
@@ -106,6 +108,9 @@ int main(int argc, char** argv) {
   run<64>(f, B, H, W, flush, sink, "128-byte pieces (an f2 chunk per workgroup)");
   run<128>(f, B, H, W, flush, sink, "256-byte pieces (the build's f1 tile)");
   run<320>(f, B, H, W, flush, sink, "whole 624-byte rows (one workgroup per image row)");
+  run<64, 1>(f, B, H, W, flush, sink, "128-byte pieces, XCD-contiguous rows");
+  run<128, 1>(f, B, H, W, flush, sink, "256-byte pieces, XCD-contiguous rows");
+  run<320, 1>(f, B, H, W, flush, sink, "whole rows, XCD-contiguous rows");
   CHECK(hipDeviceSynchronize());
   return 0;
 }
