@@ -164,26 +164,41 @@ __global__ __launch_bounds__(256) void convc1_bwd_weight_mfma_kernel(const float
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (cb_f4v)(0.f);
 
+  const T* amask = relu ? act : gact;  // block-uniform
   for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < n_groups; grp += (int64_t)gridDim.x * 4) {
     const int64_t b = grp / groups_per_image;
     const int64_t p = (grp - b * groups_per_image) * GP + g * SEG;  // this lane's pixel segment
     const bool in = p < HW;
     const int64_t pc = in ? p : 0;
     // A fragments: masked gradients of channel 16 mt + i
-    cb_u4v ga[4];
+    // (every load of a group is unconditional and issued before the first use: a load under `if (relu)` is a
+    // branch, and the compiler then waits for each one where the branches join -- 5 memory latencies per group
+    // instead of 1.  Without the ReLU the mask operand is the gradient itself, read twice, and ignored.)
+    cb_u4v ga[4], am[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       const int64_t e = (b * CB_OUT + 16 * mt + i) * HW + pc;
-      cb_u4v gv = *reinterpret_cast<const cb_u4v*>(gact + e);
-      if (relu) {
-        const cb_u4v av = *reinterpret_cast<const cb_u4v*>(act + e);
-        if constexpr (IS16) {
+      ga[mt] = *reinterpret_cast<const cb_u4v*>(gact + e);
+      am[mt] = *reinterpret_cast<const cb_u4v*>(amask + e);
+    }
+    cb_f4v craw[NT][IS16 ? 2 : 1];  // all of the group's corr segments in flight together, like the gradients
 #pragma unroll
-          for (int d = 0; d < 4; ++d) gv[d] = cb_mask_pos16(gv[d], av[d]);
-        } else {
+    for (int nt = 0; nt < NT; ++nt) {
+      const int k = 16 * nt + i;
+      const float* src = corr + (b * K + (k < K ? k : 0)) * HW + pc;
+      craw[nt][0] = *reinterpret_cast<const cb_f4v*>(src);
+      if constexpr (IS16) craw[nt][1] = *reinterpret_cast<const cb_f4v*>(src + 4);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // or the scheduler sinks the later loads behind the first MFMAs
 #pragma unroll
-          for (int d = 0; d < 4; ++d) gv[d] = __uint_as_float(av[d]) > 0.f ? gv[d] : 0u;
-        }
+    for (int mt = 0; mt < 4; ++mt) {
+      cb_u4v gv = ga[mt];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        uint32_t m;
+        if constexpr (IS16) m = cb_mask_pos16(gv[d], am[mt][d]);
+        else m = __uint_as_float(am[mt][d]) > 0.f ? gv[d] : 0u;
+        gv[d] = relu ? m : gv[d];
       }
       ga[mt] = in ? gv : (cb_u4v)(0u);
     }
@@ -192,10 +207,9 @@ __global__ __launch_bounds__(256) void convc1_bwd_weight_mfma_kernel(const float
     for (int nt = 0; nt < NT; ++nt) {
       const int k = 16 * nt + i;
       const bool real = in && k < K;
-      const float* src = corr + (b * K + (k < K ? k : 0)) * HW + pc;
       const float fill = (in && k == K) ? 1.f : 0.f;
       if constexpr (IS16) {
-        const cb_f4v c0 = *reinterpret_cast<const cb_f4v*>(src), c1 = *reinterpret_cast<const cb_f4v*>(src + 4);
+        const cb_f4v c0 = craw[nt][0], c1 = craw[nt][1];
         cb_u4v bv;
         bv[0] = cb_pack2<T>(real ? c0[0] : fill, real ? c0[1] : fill);
         bv[1] = cb_pack2<T>(real ? c0[2] : fill, real ? c0[3] : fill);
@@ -205,7 +219,7 @@ __global__ __launch_bounds__(256) void convc1_bwd_weight_mfma_kernel(const float
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = cb_mfma16<T>(__builtin_bit_cast(cb_s8v, ga[mt]), bf, acc[mt][nt]);
       } else {
-        const cb_f4v c0 = *reinterpret_cast<const cb_f4v*>(src);
+        const cb_f4v c0 = craw[nt][0];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {  // contraction slot g of step q = pixel 4 g + q, for A and B alike
           const float bq = real ? c0[q] : fill;
@@ -268,18 +282,23 @@ __global__ __launch_bounds__(256) void convc1_bwd_taps_mfma_kernel(const T* __re
     const int seg = threadIdx.x & 7;
     const int64_t p = p0 + 8 * seg;
     const bool in = p < HW;
+    cb_u4v gvs[2], avs[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int o = (threadIdx.x >> 3) + 32 * h;
-      cb_u4v gv = (cb_u4v)(0u);
-      if (in) {
-        const int64_t e = (b * CB_OUT + o) * HW + p;
-        gv = *reinterpret_cast<const cb_u4v*>(gact + e);
-        if (relu) {
-          const cb_u4v av = *reinterpret_cast<const cb_u4v*>(act + e);
+      // unconditional loads from a clamped address (see convc1_bwd_weight_mfma_kernel)
+      const int64_t e = (b * CB_OUT + o) * HW + (in ? p : 0);
+      gvs[h] = *reinterpret_cast<const cb_u4v*>(gact + e);
+      avs[h] = *reinterpret_cast<const cb_u4v*>((relu ? act : gact) + e);
+    }
 #pragma unroll
-          for (int d = 0; d < 4; ++d) gv[d] = cb_mask_pos16(gv[d], av[d]);
-        }
+    for (int h = 0; h < 2; ++h) {
+      const int o = (threadIdx.x >> 3) + 32 * h;
+      cb_u4v gv = gvs[h];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const uint32_t m = cb_mask_pos16(gv[d], avs[h][d]);
+        gv[d] = in ? (relu ? m : gv[d]) : 0u;
       }
       uint32_t* dst = reinterpret_cast<uint32_t*>(Gs + o * CB_GP + 8 * seg);
 #pragma unroll
