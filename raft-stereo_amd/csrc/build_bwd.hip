@@ -146,25 +146,65 @@ __global__ __launch_bounds__(GT) void gemm_rows_kernel(const T* __restrict__ fea
   const int srow = threadIdx.x >> 3, sseg = threadIdx.x & 7;
   const T* dCrow = dC + (int64_t)bh * W1 * ldc;
 
+  // A chunk's five 16-byte loads per thread are buffer loads at an offset that is either the piece's or past the
+  // buffer's end (which reads zeros and touches no memory): no load sits under a bounds test.  Written with
+  // `if (m < M) load`, every load was a branch of its own and the compiler waited for each one where the
+  // branches joined -- five memory latencies in a row per chunk, and none of them behind the MFMAs.  A feature
+  // row's last, partial piece (K not a multiple of the piece) is read as the 16 bytes that END at the row's end
+  // and shifted into place when the chunk is stored to LDS (the shift is the same for the whole launch).
+  const int64_t img_elems = (int64_t)M * H * K;
+  const uint32_t feat_bytes = (uint32_t)(img_elems * (int64_t)sizeof(T));
+  const uint32_t dc_bytes = (uint32_t)((int64_t)W1 * ldc * (int64_t)sizeof(T));
+  const __amdgpu_buffer_rsrc_t featR =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(feat + (int64_t)b * img_elems), 0, (int)feat_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t dcR = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(dCrow), 0, (int)dc_bytes, 0x00020000);
+  const int tail_shift_bits = (C::EPS - K % C::EPS) * 8 * (int)sizeof(T);  // used when K % EPS != 0 only
   u4v rf[4], rs;
   auto load_chunk = [&](int kc0) {
+    const int kf = kc0 + sseg * C::EPS;
+    if (vec) {  // launch-uniform: rows start on 4-byte boundaries
+      const int kl = kf + C::EPS <= K ? kf : K - C::EPS;  // the partial piece: the row's last 16 bytes instead
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int m = mb + srow + 64 * j;
-      rf[j] = (u4v)(0u);
-      if (m < M) rf[j] = load_feat<T>(feat + (((int64_t)b * M + m) * H + h) * K, kc0 + sseg * C::EPS, K, vec);
+      for (int j = 0; j < 4; ++j) {
+        const int m = mb + srow + 64 * j;
+        const uint32_t off = (uint32_t)((m * H + h) * K + kl) * (uint32_t)sizeof(T);
+        rf[j] = __builtin_amdgcn_raw_buffer_load_b128(featR, (int)((m < M && kf < K) ? off : feat_bytes), 0, 0);
+      }
+    } else {  // element by element
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int m = mb + srow + 64 * j;
+        rf[j] = (u4v)(0u);
+        if (m < M) rf[j] = load_feat<T>(feat + (((int64_t)b * M + m) * H + h) * K, kf, K, false);
+      }
     }
-    rs = (u4v)(0u);
     if constexpr (!TRANS) {
       // image [n][k]: row n0 + srow of dC, columns kc0 .. kc0 + KC
       const int n = n0 + srow, k = kc0 + sseg * C::EPS;
-      if (n < N && k < ldc) rs = *reinterpret_cast<const u4v*>(dCrow + (int64_t)n * ldc + k);
+      const uint32_t off = (uint32_t)(n * ldc + k) * (uint32_t)sizeof(T);
+      rs = __builtin_amdgcn_raw_buffer_load_b128(dcR, (int)((n < N && k < ldc) ? off : dc_bytes), 0, 0);
     } else {
       // image [k][n]: row kc0 + r of dC (a w1), columns n0 .. n0 + 64 (a 64-column row is TS / EPS segments)
       constexpr int SEGS = TS / C::EPS;
       const int r = threadIdx.x / SEGS, sg = threadIdx.x - r * SEGS;
       const int k = kc0 + r, n = n0 + sg * C::EPS;
-      if (k < K && n < ldc) rs = *reinterpret_cast<const u4v*>(dCrow + (int64_t)k * ldc + n);
+      const uint32_t off = (uint32_t)(k * ldc + n) * (uint32_t)sizeof(T);
+      rs = __builtin_amdgcn_raw_buffer_load_b128(dcR, (int)((k < K && n < ldc) ? off : dc_bytes), 0, 0);
+    }
+  };
+  // the partial piece of chunk kc0, loaded as the row's last 16 bytes: move its first K - kf elements to the front
+  auto fix_tail = [&](int kc0) {
+    const int kf = kc0 + sseg * C::EPS;
+    const bool tail = vec && kf < K && kf + C::EPS > K;
+    if (!__any(tail)) return;  // wave-uniform; no loads inside
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint64_t lo = (uint64_t)rf[j][0] | ((uint64_t)rf[j][1] << 32), hi = (uint64_t)rf[j][2] | ((uint64_t)rf[j][3] << 32);
+      const int sb = tail_shift_bits;  // 1 .. 127, block-uniform
+      const uint64_t nlo = sb >= 64 ? hi >> (sb - 64) : (lo >> sb) | (hi << (64 - sb));
+      const uint64_t nhi = sb >= 64 ? 0ull : hi >> sb;
+      const u4v sh = {(uint32_t)nlo, (uint32_t)(nlo >> 32), (uint32_t)nhi, (uint32_t)(nhi >> 32)};
+      rf[j] = tail ? sh : rf[j];
     }
   };
   auto store_chunk = [&]() {
@@ -190,6 +230,7 @@ __global__ __launch_bounds__(GT) void gemm_rows_kernel(const T* __restrict__ fea
   load_chunk(0);
   for (int kc0 = 0; kc0 < K; kc0 += C::KC) {
     __syncthreads();  // previous chunk's readers are done
+    fix_tail(kc0);
     store_chunk();
     __syncthreads();
     if (kc0 + C::KC < K) load_chunk(kc0 + C::KC);
@@ -323,10 +364,17 @@ int run_gemms(const void* dCv, const rc_layout* lay, const void* f1, const void*
   const T* dC = reinterpret_cast<const T*>(dCv);
   const int my = (D + TMF - 1) / TMF;
   const int64_t rows8 = (BH + 7) / 8 * 8;
-  const bool v2 = (W2 * sizeof(T)) % 4 == 0 && (uintptr_t)f2 % 4 == 0;
-  const bool v1 = (W1 * sizeof(T)) % 4 == 0 && (uintptr_t)f1 % 4 == 0;
+  // 16-byte pieces: rows on 4-byte boundaries and at least one piece long (a partial last piece is read as the
+  // row's last 16 bytes)
+  constexpr int EPS = 16 / (int)sizeof(T);
+  const bool v2 = (W2 * sizeof(T)) % 4 == 0 && (uintptr_t)f2 % 4 == 0 && W2 >= EPS;
+  const bool v1 = (W1 * sizeof(T)) % 4 == 0 && (uintptr_t)f1 % 4 == 0 && W1 >= EPS;
   const int ns1 = (W1 + TS - 1) / TS, ns2 = (W2 + TS - 1) / TS;
   RC_REQUIRE(rows8 * (ns1 > ns2 ? ns1 : ns2) * my < (1ll << 31), RC_EINVAL, "grid too large");
+  // the kernel addresses one image's feature maps and one row's dC through 32-bit buffer offsets
+  RC_REQUIRE((int64_t)D * H * (W1 > W2 ? W1 : W2) * (int64_t)sizeof(T) < (1ll << 31) &&
+                 (int64_t)W1 * W2p * (int64_t)sizeof(T) < (1ll << 31),
+             RC_EUNSUPPORTED, "one image's feature maps (or one row's dense gradient) exceed 2 GiB");
   // d fmap1 = f2 . dC^T : n = w1, k = w2
   hipLaunchKernelGGL((gemm_rows_kernel<T, false>), dim3((unsigned)(rows8 * ns1 * my), 1, 1), dim3(GT), 0, st,
                      (const T*)f2, dC, (T*)df1, D, W1, W2, H, W1, W2p, v2, ns1, my, (int)BH);

@@ -983,27 +983,44 @@ __global__ __launch_bounds__(PW_THREADS) void pool2x_kernel(const T* __restrict_
   float acc[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+  // Every load is unconditional, from a clamped row / column, and what lies outside the image is zeroed after:
+  // a load under a bounds test is a branch, and the compiler waits for each one where the branches join (one
+  // memory latency per load instead of one per thread).
+  float in[3][2 * VEC + 1];
+  if (vec_in) {  // launch-uniform: input rows are whole, aligned vectors of 2 VEC elements
+    typename pw_vec<T, 2 * VEC>::type vr[3];
+    T left[3];
 #pragma unroll
-  for (int dy = -1; dy <= 1; ++dy) {
-    const int h = 2 * ho + dy;
-    if ((unsigned)h >= (unsigned)H) continue;
-    const T* row = src + (int64_t)h * W;
-    // the 2 VEC + 1 inputs under this thread's outputs: columns 2 wo0 - 1 .. 2 wo0 + 2 VEC - 1
-    float in[2 * VEC + 1];
-    if (vec_in) {  // launch-uniform: input rows are whole, aligned vectors of 2 VEC elements
-      const auto vr = pw_load<T, 2 * VEC>(row + 2 * wo0);
-      in[0] = wo0 > 0 ? rc_to_float(row[2 * wo0 - 1]) : 0.f;
-#pragma unroll
-      for (int q = 0; q < 2 * VEC; ++q) in[q + 1] = rc_to_float(vr[q]);
-    } else {
-#pragma unroll
-      for (int q = 0; q < 2 * VEC + 1; ++q) {
-        const int w = 2 * wo0 - 1 + q;
-        in[q] = (unsigned)w < (unsigned)W ? rc_to_float(row[w]) : 0.f;
-      }
+    for (int dy = -1; dy <= 1; ++dy) {
+      const T* row = src + (int64_t)min(max(2 * ho + dy, 0), H - 1) * W;
+      vr[dy + 1] = pw_load<T, 2 * VEC>(row + 2 * wo0);
+      left[dy + 1] = row[max(2 * wo0 - 1, 0)];
     }
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) acc[j] += (in[2 * j] + in[2 * j + 1]) + in[2 * j + 2];
+    for (int d = 0; d < 3; ++d) {
+      in[d][0] = wo0 > 0 ? rc_to_float(left[d]) : 0.f;
+#pragma unroll
+      for (int q = 0; q < 2 * VEC; ++q) in[d][q + 1] = rc_to_float(vr[d][q]);
+    }
+  } else {
+    T raw[3][2 * VEC + 1];
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+      const T* row = src + (int64_t)min(max(2 * ho + dy, 0), H - 1) * W;
+#pragma unroll
+      for (int q = 0; q < 2 * VEC + 1; ++q) raw[dy + 1][q] = row[min(max(2 * wo0 - 1 + q, 0), W - 1)];
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+      for (int q = 0; q < 2 * VEC + 1; ++q)
+        in[d][q] = (unsigned)(2 * wo0 - 1 + q) < (unsigned)W ? rc_to_float(raw[d][q]) : 0.f;
+  }
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy) {
+    if ((unsigned)(2 * ho + dy) >= (unsigned)H) continue;  // (no loads inside: a plain skip of three additions)
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] += (in[dy + 1][2 * j] + in[dy + 1][2 * j + 1]) + in[dy + 1][2 * j + 2];
   }
   typename pw_vec<T, VEC>::type o;
 #pragma unroll

@@ -264,6 +264,36 @@ def test_16bit_backward(R, golden, dtype):
     assert rel(f1.grad, rd1) < TOL16[dtype] and rel(f2.grad, rd2) < TOL16[dtype]
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("shape", [(1, 32, 2, 20, 44), (2, 64, 1, 180, 180), (1, 16, 3, 12, 10), (1, 40, 2, 9, 14),
+                                   (1, 24, 2, 8, 17), (2, 300, 1, 36, 28)])
+def test_build_backward_rows_that_end_in_a_partial_piece(R, dtype, shape):
+    """The contractions of the build's adjoint read feature rows in 16-byte pieces; a row that does not end on a
+    piece boundary has its last piece read as the row's last 16 bytes and shifted into place (build_bwd.hip).
+    Widths that are / are not multiples of the piece (8 elements of 16 bits, 4 of fp32), rows shorter than two
+    pieces, odd widths (16-bit rows off the 4-byte grid: the element path), more channels than one workgroup takes:
+    against the oracle on the rounded inputs."""
+    B, D, H, W1, W2 = shape
+    L, r = 2, 2
+    rng = np.random.default_rng(W1 * 100 + W2)
+    f1n = rng.standard_normal((B, D, H, W1)).astype(np.float32)
+    f2n = rng.standard_normal((B, D, H, W2)).astype(np.float32)
+    coords = O.synthetic_coords(B, H, W1, seed=3)
+    coords[:, 0] *= W2 / W1
+    gout = rng.standard_normal((B, L * (2 * r + 1), H, W1)).astype(np.float32)
+    f1r, f2r = (f1n, f2n) if dtype == torch.float32 else (_round(f1n, dtype), _round(f2n, dtype))
+    widths = [W2 >> i for i in range(L)]
+    lg = O.lookup_bwd(coords, gout, widths, r, O.EXACT)
+    rd1, rd2 = O.corr_volume_bwd(O.pool_pyramid_bwd(lg), f1r, f2r)
+    f1 = dev(f1n, dtype).requires_grad_(True)
+    f2 = dev(f2n, dtype).requires_grad_(True)
+    blk = R.CorrBlock1DHip(f1, f2, num_levels=L, radius=r, coord_mode="exact")
+    (blk(dev(coords)) * dev(gout)).sum().backward()
+    tol = TOL32 if dtype == torch.float32 else TOL16[dtype]
+    assert rel(f1.grad, rd1) < tol and rel(f2.grad, rd2) < tol
+    assert f1.grad.abs().max() > 0 and f2.grad.abs().max() > 0
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("mode", ["exact", "gridsample"])
 @pytest.mark.parametrize("shape,L,r", [((2, 64, 3, 45, 45), 4, 4), ((1, 32, 2, 131, 70), 3, 2), ((1, 32, 5, 64, 257), 2, 7),
