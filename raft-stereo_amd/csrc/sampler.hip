@@ -69,17 +69,22 @@ __global__ __launch_bounds__(SP_THREADS) void sampler_bwd_vec_kernel(const float
   uint32_t n = pix0 / (uint32_t)HW, q = pix0 - n * (uint32_t)HW;  // wave-uniform
   typedef uint32_t u4 __attribute__((ext_vector_type(4)));
   float xs[SP_RPW], gs[SP_RPW];
+  T graw[SP_RPW];
+  const int tap = lane < rd ? lane : 0;
 #pragma unroll
-  for (int k = 0; k < SP_RPW; ++k) {  // the rows' coordinates and gradients first: 2 SP_RPW loads in flight
-    const bool have = pix0 + k < n_pix;  // wave-uniform
-    xs[k] = have ? coords[((int64_t)n * coords_channels) * HW + q] : 0.f;
-    // lane j < 2r+1 holds the pixel's gradient of tap j
-    gs[k] = have && lane < rd ? rc_to_float(corr_grad[((int64_t)n * rd + lane) * HW + q]) : 0.f;
-    if (++q == (uint32_t)HW) {
+  for (int k = 0; k < SP_RPW; ++k) {  // the rows' coordinates and gradients first: 2 SP_RPW loads in flight, all
+    // unconditional (rows past the end re-read the last one; lanes past the taps read tap 0): a load under a
+    // test is a branch, and the compiler waits for each one where it joins
+    xs[k] = coords[((int64_t)n * coords_channels) * HW + q];
+    graw[k] = corr_grad[((int64_t)n * rd + tap) * HW + q];
+    if (pix0 + k + 1 < n_pix && ++q == (uint32_t)HW) {
       q = 0;
       ++n;
     }
   }
+#pragma unroll
+  for (int k = 0; k < SP_RPW; ++k)  // lane j < 2r+1 holds the pixel's gradient of tap j
+    gs[k] = (pix0 + k < n_pix && lane < rd) ? rc_to_float(graw[k]) : 0.f;
 #pragma unroll
   for (int k = 0; k < SP_RPW; ++k) {
     if (pix0 + k >= n_pix) break;  // wave-uniform

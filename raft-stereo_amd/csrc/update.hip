@@ -497,14 +497,23 @@ __global__ __launch_bounds__(PW_THREADS) void upsample_bwd_flow_kernel(const flo
   const int h = (int)(r % H);
   const int64_t n = r / H;
   const int64_t HW = (int64_t)H * W;
+  // all 9 C loads unconditional, from a clamped neighbour (a load under the bounds test is a branch, and the
+  // compiler waits for each one where it joins); what lies outside the image is dropped after
+  float v[C][9];
+#pragma unroll
+  for (int c = 0; c < C; ++c)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int hs = min(max(h - (k / 3) + 1, 0), H - 1), ws = min(max(w - (k % 3) + 1, 0), W - 1);
+      v[c][k] = work[((n * C + c) * 9 + k) * HW + (int64_t)hs * W + ws];
+    }
 #pragma unroll
   for (int c = 0; c < C; ++c) {
     float acc = 0.f;
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
       const int hs = h - (k / 3) + 1, ws = w - (k % 3) + 1;  // the pixel whose k-th neighbour is (h, w)
-      if ((unsigned)hs < (unsigned)H && (unsigned)ws < (unsigned)W)
-        acc += work[((n * C + c) * 9 + k) * HW + (int64_t)hs * W + ws];
+      if ((unsigned)hs < (unsigned)H && (unsigned)ws < (unsigned)W) acc += v[c][k];
     }
     dflow[n * dflow_bs + (int64_t)c * HW + (int64_t)h * W + w] = factor * acc;
   }
@@ -771,10 +780,17 @@ __global__ __launch_bounds__(PW_THREADS) void seqloss_partial_kernel(sl_ptrs ptr
       ok[e] = (va[e] >= 0.5f) && (sqrtf(g[e] * g[e]) < max_flow);
       cnt += ok[e] ? 1.f : 0.f;
     }
+    // all of the chunk's predictions first (the loads of later ones do not move above the branch that consumes an
+    // earlier one by themselves: one memory latency per prediction instead of one per pixel step)
+    fv xs[SL_P];
 #pragma unroll
     for (int j = 0; j < SL_P; ++j) {
       const int i = min(i0 + j, n - 1);  // past the end: re-read the last one, not accumulated
-      const fv x = pw_load<float, VEC>(ptrs.pred[i] + b * pred_bs + q);
+      xs[j] = pw_load<float, VEC>(ptrs.pred[i] + b * pred_bs + q);
+    }
+#pragma unroll
+    for (int j = 0; j < SL_P; ++j) {
+      const fv x = xs[j];
       if (i0 + j < n) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
