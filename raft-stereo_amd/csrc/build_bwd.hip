@@ -121,10 +121,11 @@ __device__ __forceinline__ u4v load_feat(const T* __restrict__ row, int k, int K
 // LDS in chunks of KC along k with coalesced 16-byte loads (the next chunk is in flight during the
 // MFMAs).  The MFMA rows are n and its columns are the channels, so a lane ends up with 4
 // consecutive n of one channel: one 8-byte store.
-template <typename T, bool TRANS>
+template <typename T, bool TRANS, bool VEC>
 __global__ __launch_bounds__(GT) void gemm_rows_kernel(const T* __restrict__ feat, const T* __restrict__ dC,
                                                        T* __restrict__ out, int M, int N, int K, int H, int W1,
-                                                       int ldc, bool vec, int n_slabs, int n_mgroups, int n_rows) {
+                                                       int ldc, int n_slabs, int n_mgroups, int n_rows) {
+  constexpr bool vec = VEC;  // feature rows on 4-byte boundaries and at least one 16-byte piece long
   using C = gemm_cfg<T>;
   __shared__ __attribute__((aligned(16))) T featI[C::FEAT_ELEMS];
   __shared__ __attribute__((aligned(16))) T slabI[C::SLAB_ELEMS];
@@ -376,13 +377,17 @@ int run_gemms(const void* dCv, const rc_layout* lay, const void* f1, const void*
                  (int64_t)W1 * W2p * (int64_t)sizeof(T) < (1ll << 31),
              RC_EUNSUPPORTED, "one image's feature maps (or one row's dense gradient) exceed 2 GiB");
   // d fmap1 = f2 . dC^T : n = w1, k = w2
-  hipLaunchKernelGGL((gemm_rows_kernel<T, false>), dim3((unsigned)(rows8 * ns1 * my), 1, 1), dim3(GT), 0, st,
-                     (const T*)f2, dC, (T*)df1, D, W1, W2, H, W1, W2p, v2, ns1, my, (int)BH);
+#define RC_GEMM_ROWS(TRANS, VEC, feat, out, N, K, ns)                                                             \
+  hipLaunchKernelGGL((gemm_rows_kernel<T, TRANS, VEC>), dim3((unsigned)(rows8 * (ns) * my), 1, 1), dim3(GT), 0, st, \
+                     (const T*)(feat), dC, (T*)(out), D, N, K, H, W1, W2p, ns, my, (int)BH)
+  if (v2) RC_GEMM_ROWS(false, true, f2, df1, W1, W2, ns1);
+  else RC_GEMM_ROWS(false, false, f2, df1, W1, W2, ns1);
   int rc = rc_check_launch("rc_build_bwd(df1)");
   if (rc) return rc;
   // d fmap2 = f1 . dC : n = w2, k = w1
-  hipLaunchKernelGGL((gemm_rows_kernel<T, true>), dim3((unsigned)(rows8 * ns2 * my), 1, 1), dim3(GT), 0, st,
-                     (const T*)f1, dC, (T*)df2, D, W2, W1, H, W1, W2p, v1, ns2, my, (int)BH);
+  if (v1) RC_GEMM_ROWS(true, true, f1, df2, W2, W1, ns2);
+  else RC_GEMM_ROWS(true, false, f1, df2, W2, W1, ns2);
+#undef RC_GEMM_ROWS
   return rc_check_launch("rc_build_bwd(df2)");
 }
 
