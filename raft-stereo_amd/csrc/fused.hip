@@ -201,14 +201,22 @@ __global__ __launch_bounds__(FC_THREADS) void lookup_convc1_kernel(const VT* __r
   float x = (coords + uniform(((int64_t)b * coords_channels) * HW))[pidx];
   if (upd.coords_out) {  // wave-uniform: the GRU iteration's coordinate glue (core/raft_stereo.py:109-111, :120-123)
     const int64_t q0 = uniform(((int64_t)b * 2) * HW);
+    // x, the delta and y are requested together and converted after (a value used inside the branch that loads
+    // it is waited for there: three memory latencies in a row before the pyramid's loads could start)
+    uint32_t draw = 0;
+    if (upd.delta) {
+      if (upd.delta_dtype == RC_F32) draw = (reinterpret_cast<const uint32_t*>(upd.delta) + q0)[pidx];
+      else draw = (reinterpret_cast<const uint16_t*>(upd.delta) + q0)[pidx];
+    }
+    float y = (float)h;
+    if (coords_channels > 1) y = (coords + uniform(((int64_t)b * coords_channels + 1) * HW))[pidx];
     if (upd.delta) {  // coords1 = coords1 + (delta_flow[:,0], 0): the fp32 add of the reference (delta promoted)
       float dlt;
-      if (upd.delta_dtype == RC_F32) dlt = (reinterpret_cast<const float*>(upd.delta) + q0)[pidx];
-      else if (upd.delta_dtype == RC_F16) dlt = (float)(reinterpret_cast<const rc_half*>(upd.delta) + q0)[pidx];
-      else dlt = (float)(reinterpret_cast<const rc_bf16*>(upd.delta) + q0)[pidx];
+      if (upd.delta_dtype == RC_F32) dlt = __uint_as_float(draw);
+      else if (upd.delta_dtype == RC_F16) dlt = (float)__builtin_bit_cast(rc_half, (uint16_t)draw);
+      else dlt = __uint_as_float(draw << 16);
       x += dlt;
     }
-    const float y = coords_channels > 1 ? (coords + uniform(((int64_t)b * coords_channels + 1) * HW))[pidx] : (float)h;
     if (it.p0 + poff < (int)HW) {  // lanes past the end of the image repeat its last pixel and store nothing
       (upd.coords_out + q0)[pidx] = x;
       (upd.coords_out + uniform(q0 + HW))[pidx] = y;

@@ -98,9 +98,10 @@ __global__ __launch_bounds__(LK_THREADS) void lookup_fwd_kernel(const VT* __rest
     // core/raft_stereo.py:120-123 (delta_flow[:,1] = 0; coords1 = coords1 + delta_flow) and :111
     // (flow = coords1 - coords0, coords0 = the pixel grid of core/utils/utils.py coords_grid)
     const int64_t q0 = uniform(((int64_t)b * 2) * HW + it.p0);
-    x += (upd.delta + q0)[lane];
-    const float y = coords_channels > 1 ? (coords + uniform(((int64_t)b * coords_channels + 1) * HW + it.p0))[lane]
-                                        : (float)h;
+    const float dlt = (upd.delta + q0)[lane];  // x, the delta and y are requested together
+    float y = (float)h;
+    if (coords_channels > 1) y = (coords + uniform(((int64_t)b * coords_channels + 1) * HW + it.p0))[lane];
+    x += dlt;
     (upd.coords_out + q0)[lane] = x;
     (upd.coords_out + uniform(q0 + HW))[lane] = y;
     (upd.flow_out + q0)[lane] = x - (float)w1;
