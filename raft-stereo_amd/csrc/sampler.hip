@@ -34,12 +34,22 @@ __global__ __launch_bounds__(SP_THREADS) void sampler_fwd_kernel(const T* __rest
   const T* row = volume + pix * W2;
   // all 2r+2 loads unconditional, from a clamped column (a load under the bounds test is a branch, and the compiler
   // then waits for every one before issuing the next: 2r+2 memory latencies per pixel for the 16-bit types)
-  T raw[rd + 1];
-#pragma unroll
-  for (int j = 0; j <= rd; ++j) raw[j] = row[min(max(base + j, 0), W2 - 1)];
+  // (fp32: the compiler issues the conditional loads back to back by itself, and skipping the columns outside the
+  // image saves their lines: 13.4 against 14.8 us at the KITTI size)
   float sv[rd + 1];
+  if constexpr (sizeof(T) == 4) {
 #pragma unroll
-  for (int j = 0; j <= rd; ++j) sv[j] = (unsigned)(base + j) < (unsigned)W2 ? rc_to_float(raw[j]) : 0.f;
+    for (int j = 0; j <= rd; ++j) {
+      const int x1 = base + j;
+      sv[j] = (unsigned)x1 < (unsigned)W2 ? rc_to_float(row[x1]) : 0.f;
+    }
+  } else {
+    T raw[rd + 1];
+#pragma unroll
+    for (int j = 0; j <= rd; ++j) raw[j] = row[min(max(base + j, 0), W2 - 1)];
+#pragma unroll
+    for (int j = 0; j <= rd; ++j) sv[j] = (unsigned)(base + j) < (unsigned)W2 ? rc_to_float(raw[j]) : 0.f;
+  }
   // corr[j] = s_j * (1 - dx) + s_{j+1} * dx, each product and the sum rounded to T
   const float wa = rc_round_as<T>(1.0f - dx), wb = rc_round_as<T>(dx);
   T* o = corr + (n * rd) * HW + q;
