@@ -150,7 +150,10 @@ __global__ __launch_bounds__(256) void alt_fwd_kernel(const T* __restrict__ f1t,
   // a pixel's run of correlation values at the wave's even level: slot j <-> w2 = rs + j
   __shared__ float win[4][16][PITCH];
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // (wave through readfirstlane: the level-indexed kernel arguments below are then scalar loads; indexed by a
+  // value the compiler takes for per-lane they were vector loads issued after the feature loads, and the first
+  // block of f2 waited for all of them plus one more round trip for its offset)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, li = lane & 15;
   // A workgroup owns 32 consecutive pixels of one image row: wave = (block of 16 pixels, pair of levels).  A run
   // needs 2-4 operand blocks, the two waves of a pixel block share its operand through the L1.  Workgroup ids
@@ -169,6 +172,10 @@ __global__ __launch_bounds__(256) void alt_fwd_kernel(const T* __restrict__ f1t,
   const int nkc = FULL ? NKC : lay.Dp / KCH;
   const int64_t blk_elems = (int64_t)nkc * 64 * EL;  // one block of 16 positions, all channels
 
+  // the coordinate first: loads return in order, and the first block of f2 can be asked for as soon as x is here,
+  // while the pixels' own features are still on their way
+  const float x = coords[((int64_t)b * coords_channels) * HW + (int64_t)h * lay.W1 + w1c];
+  __builtin_amdgcn_sched_barrier(0);
   // the pixels' feature vectors as MFMA B operands (columns = pixels)
   uint4 bfrag[NKC];
   {
@@ -179,7 +186,7 @@ __global__ __launch_bounds__(256) void alt_fwd_kernel(const T* __restrict__ f1t,
       else bfrag[kc] = kc < nkc ? *reinterpret_cast<const uint4*>(p + kc * 64 * EL) : make_uint4(0, 0, 0, 0);
     }
   }
-  const float x = coords[((int64_t)b * coords_channels) * HW + (int64_t)h * lay.W1 + w1c];
+  __builtin_amdgcn_sched_barrier(0);
 
   const int Wlo = lay.width[i], Whi = has_hi ? lay.width[i + 1] : 0;
   const float x_lo = x / (float)(1 << i), x_hi = x / (float)(2 << i);
