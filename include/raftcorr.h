@@ -202,6 +202,9 @@ int rc_build_bwd(const float* grad_vol, const rc_layout* glay, const void* f1, c
  * then contracts it with the feature maps (autograd of corr.py:154-156); df1/df2 and dense_grad
  * have the feature dtype.  A thread owns the per-level gradient row of its pixel (in LDS, f32) and
  * adds the lookups in list order: no atomics, results are reproducible run to run.
+ * Limits (RC_EUNSUPPORTED / RC_EINVAL beyond them): one image's gradient planes L*(2r+1)*H*W1 < 2^29
+ * elements (rc_lookup_bwd_dense); one image's feature maps D*H*max(W1,W2) and one row's dense gradient
+ * W1*ld below 2 GiB (rc_build_bwd, rc_build_bwd_dense: 32-bit buffer offsets inside an image).
  */
 int64_t rc_dense_grad_ld(const rc_layout* glay);
 int rc_lookup_bwd_dense(const float* const* coords_list, const float* const* grad_out_list,
