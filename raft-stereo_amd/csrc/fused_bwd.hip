@@ -42,11 +42,13 @@ __global__ __launch_bounds__(256) void convc1_bwd_taps_kernel(const T* __restric
   const int64_t b = blockIdx.y;
   const T* a0 = act + b * CB_OUT * HW + p;
   const T* g0 = gact + b * CB_OUT * HW + p;
+  const T* am = relu ? a0 : g0;  // both planes are read unconditionally (see convc1_bwd_weight_kernel)
   float gm[CB_OUT];
 #pragma unroll
   for (int o = 0; o < CB_OUT; ++o) {
     const float g = rc_to_float(g0[(int64_t)o * HW]);
-    gm[o] = (!relu || rc_to_float(a0[(int64_t)o * HW]) > 0.f) ? g : 0.f;
+    const float a = rc_to_float(am[(int64_t)o * HW]);
+    gm[o] = (!relu || a > 0.f) ? g : 0.f;
   }
   float* dst = gcorr + b * K * HW + p;
   for (int k = 0; k < K; ++k) {
@@ -79,18 +81,27 @@ __global__ __launch_bounds__(256) void convc1_bwd_weight_kernel(const float* __r
     const int64_t b = c / chunks_per_image, p = (c - b * chunks_per_image) * CB_PIX + px;
     const bool in = p < HW;
     __syncthreads();  // the previous chunk has been consumed
+    // unconditional loads from a clamped pixel, selected after (a load under `if (in)` / `if (relu)` is a branch and
+    // the compiler waits for each one where it joins: 32 memory latencies in a row per chunk)
+    const int64_t pc = in ? p : 0;
+    const T* amask = relu ? act : gact;
+    T graw[CB_OUT / 4], araw[CB_OUT / 4];
 #pragma unroll
     for (int i = 0; i < CB_OUT / 4; ++i) {
-      const int oo = r0 + 4 * i;
-      float g = 0.f;
-      if (in) {
-        const int64_t e = (b * CB_OUT + oo) * HW + p;
-        g = rc_to_float(gact[e]);
-        if (relu && !(rc_to_float(act[e]) > 0.f)) g = 0.f;
-      }
-      Gs[oo][px] = g;
+      const int64_t e = (b * CB_OUT + r0 + 4 * i) * HW + pc;
+      graw[i] = gact[e];
+      araw[i] = amask[e];
     }
-    for (int kk = r0; kk < K; kk += 4) Cs[kk][px] = in ? corr[(b * K + kk) * HW + p] : 0.f;
+#pragma unroll
+    for (int i = 0; i < CB_OUT / 4; ++i) {
+      float g = rc_to_float(graw[i]);
+      if (relu && !(rc_to_float(araw[i]) > 0.f)) g = 0.f;
+      Gs[r0 + 4 * i][px] = in ? g : 0.f;
+    }
+    for (int kk = r0; kk < K; kk += 4) {
+      const float cv = corr[(b * K + kk) * HW + pc];
+      Cs[kk][px] = in ? cv : 0.f;
+    }
     __syncthreads();
 #pragma unroll 4
     for (int q = 0; q < CB_PIX; ++q) {
