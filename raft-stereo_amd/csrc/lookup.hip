@@ -448,6 +448,9 @@ __global__ __launch_bounds__(RC_MAX_LEVELS * TP) void adjoint_dense_kernel(adj_l
 #ifndef RC_LAB_ADJ_ABLATE
 #define RC_LAB_ADJ_ABLATE 0
 #endif
+#ifndef RC_LAB_ADJ_LOAD_AUX  // lab: cache policy of the gradient-plane loads (0 plain, 2 non-temporal, 1 / 3 with sc0)
+#define RC_LAB_ADJ_LOAD_AUX 0
+#endif
   constexpr int PD = RC_LAB_ADJ_PD;
   float xs[PD], gs[PD][NT];
   // buffer loads: descriptor from the uniform base (scalar work), the lane's precomputed byte offset as it is -- a
@@ -465,7 +468,7 @@ __global__ __launch_bounds__(RC_MAX_LEVELS * TP) void adjoint_dense_kernel(adj_l
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(lists.gout[tc] + gu), 0, size, 0x00020000);
 #pragma unroll
     for (int k = 0; k < NT; ++k)
-      gs[slot][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff[k], 0, 0));
+      gs[slot][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff[k], 0, RC_LAB_ADJ_LOAD_AUX));
   };
   float lab_sum = 0.f;
   // the first PD lookups are asked for before the rows are cleared: their latency passes behind the clearing
