@@ -463,6 +463,16 @@ __global__ __launch_bounds__(BT16, 4) void build16_kernel(const T* __restrict__ 
 
 // ---- 16-bit feature maps whose rows are whole 16-byte segments (W1, W2 multiples of 8, D = 256): the f2 stream and
 // the f1 tile go global -> LDS by LDS-DMA (global_load_lds_dwordx4), no staging registers and no ds_write pass.
+#ifndef RC_LAB_BUILD_DMA_POLICY  // lab: cache policy of the DMA loads of f2 ("" plain, " nt", " sc1", ...)
+#define RC_LAB_BUILD_DMA_POLICY ""
+#endif
+// f1 (glds16<true>): non-temporal.  A workgroup's f1 tile has no other reader, and left in the Infinity Cache its
+// 123 MB (KITTI, 8 pairs) push out pyramid lines the lookups are about to read: with " nt" the build itself takes
+// 108.8 instead of 111 us in a step and each of the 32 lookups 9.2-9.4 instead of 9.5 us.  (The same policy on f2,
+// which the three tiles of a row all read, costs the build 30 us: its re-reads then miss.)
+#ifndef RC_LAB_BUILD_F1_POLICY
+#define RC_LAB_BUILD_F1_POLICY " nt"
+#endif
 // That frees the registers for 32-column wave tiles: 8 waves = 4 column groups x 2 halves of the 64-row chunk,
 // every f2 fragment read from LDS feeds TWO MFMAs (the 16-column kernel above reads every fragment for one: its
 // MFMA phase is bound by LDS bandwidth, 2 200 cycles per chunk where the matrix pipe needs 1 000:
@@ -477,18 +487,26 @@ constexpr int G_ROW = 128;           // bytes per LDS row: 64 elements
 constexpr int G_BUF = KMAX * G_ROW;  // one staged tile: 32 KiB
 
 // one DMA instruction: lane l fetches 16 bytes from gsrc, they land at lds_dst + 16 l (lds_dst wave-uniform)
+// ONCE: the data has one reader (a workgroup's own f1 tile)
+template <bool ONCE = false>
 __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(gsrc), "s"(lds_dst)
-               : "memory");
+  if constexpr (ONCE)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" RC_LAB_BUILD_F1_POLICY "\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" RC_LAB_BUILD_DMA_POLICY "\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
 }
 
 // [256 k][64 columns from n0] of one image row -> the LDS tile at byte address lds_buf: 4 DMA instructions per
 // wave, instruction p of wave w fills rows 64 p + 8 w .. + 7.  Segments past the end of the row re-read its start
 // (what they produce lands in padding cells or in columns that are not stored).
-template <typename T>
+template <typename T, bool ONCE = false>
 __device__ __forceinline__ void dma_tile(const T* rowbase, int64_t kstride, int W, int n0, uint32_t lds_buf, int wave) {
   const int lane = threadIdx.x & 63;
   const int kr = lane >> 3;
@@ -498,7 +516,7 @@ __device__ __forceinline__ void dma_tile(const T* rowbase, int64_t kstride, int 
   const T* src = rowbase + (int64_t)(wave * 8 + kr) * kstride + col;
 #pragma unroll
   for (int p = 0; p < 4; ++p)
-    glds16(src + (int64_t)p * 64 * kstride, lds_buf + (uint32_t)((p * 64 + wave * 8) * G_ROW));
+    glds16<ONCE>(src + (int64_t)p * 64 * kstride, lds_buf + (uint32_t)((p * 64 + wave * 8) * G_ROW));
 }
 
 // byte offset inside a swizzled tile of this lane's transposed-read address for the 16 columns from `co`
@@ -591,7 +609,8 @@ __device__ __forceinline__ void epilogue16_g(const f4v (&acc)[2][2], float scale
   slab_store16<2>(s2, blk_bytes, g < 2 ? W1 : 0, col_sw, n0 >> 5, d0, d1, d2, d3);
 }
 
-template <typename T>
+// F1_ONCE: the f1 tile is fetched non-temporally (glds16; the launcher decides by the pyramid's size)
+template <typename T, bool F1_ONCE>
 __global__ __launch_bounds__(BT16, 4) void build16g_kernel(const T* __restrict__ f1, const T* __restrict__ f2,
                                                            T* __restrict__ vol, rc_dev_layout lay, float scale,
                                                            int n_tiles, int n_rows) {
@@ -632,8 +651,8 @@ __global__ __launch_bounds__(BT16, 4) void build16g_kernel(const T* __restrict__
 #pragma unroll
     for (int p = 0; p < 4; ++p) c0regs[p] = *reinterpret_cast<const u4v*>(src + (int64_t)p * 64 * ks2);
   }
-  dma_tile<T>(f1row, ks1, W1, c0, lds0, wave);
-  dma_tile<T>(f1row, ks1, W1, c0 + 64, lds0 + G_BUF, wave);
+  dma_tile<T, F1_ONCE>(f1row, ks1, W1, c0, lds0, wave);
+  dma_tile<T, F1_ONCE>(f1row, ks1, W1, c0 + 64, lds0 + G_BUF, wave);
   RC_STAMP(1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -982,7 +1001,10 @@ int launch_build(const void* f1, const void* f2, void* vol, const rc_layout* lay
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&build16_kernel<T, 2>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * C::LDS_BYTES);
       if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&build16g_kernel<T>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&build16g_kernel<T, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G_BUF);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&build16g_kernel<T, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G_BUF);
     }
     if (e != hipSuccess) {
@@ -1015,8 +1037,14 @@ int launch_build(const void* f1, const void* f2, void* vol, const rc_layout* lay
     bool dma = fast && whole && lay->W1 % 8 == 0 && lay->W2 % 8 == 0 && ((uintptr_t)f1) % 16 == 0 &&
                ((uintptr_t)f2) % 16 == 0 && !getenv("RC_BUILD_NO_DMA");
     for (int i = 0; i < lay->L; i += 2) dma = dma && d.bias[i] <= 3 * (lay->widthp[i] / 8);
-    if (dma)
-      hipLaunchKernelGGL((build16g_kernel<T>), dim3((unsigned)blocks), dim3(BT16), 2 * G_BUF, st, (const T*)f1,
+    // a pyramid that can stay in the 256 MiB Infinity Cache for the lookups is worth protecting from the f1 stream
+    // (see glds16); a larger one is not, and there the non-temporal f1 costs the build 8 % (64 KITTI pairs)
+    const bool f1_once = lay->total * (int64_t)sizeof(T) <= (200ll << 20) && !getenv("RC_BUILD_F1_PLAIN");
+    if (dma && f1_once)
+      hipLaunchKernelGGL((build16g_kernel<T, true>), dim3((unsigned)blocks), dim3(BT16), 2 * G_BUF, st, (const T*)f1,
+                         (const T*)f2, (T*)vol, d, scale, n_tiles, n_rows);
+    else if (dma)
+      hipLaunchKernelGGL((build16g_kernel<T, false>), dim3((unsigned)blocks), dim3(BT16), 2 * G_BUF, st, (const T*)f1,
                          (const T*)f2, (T*)vol, d, scale, n_tiles, n_rows);
     else if (fast && whole) RC_LAUNCH_BUILD16(2);
     else if (fast) RC_LAUNCH_BUILD16(1);
