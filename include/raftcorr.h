@@ -133,6 +133,9 @@ int rc_grad_pyramid_layout(int64_t B, int64_t H, int64_t W1, int64_t W2, int L, 
  * inputs the 16x16x32 f16/bf16 MFMA with f32 accumulation; levels >= 1 are means of the
  * already-rounded lower level (what avg_pool2d on a 16-bit volume does, corr.py:42).
  * Supported: (in,vol) = (F32,F32), (F16,F16), (BF16,BF16), (F16|BF16, F32).
+ * Environment (read per call; cache policy and kernel choice only, the results are the same bits):
+ * RC_BUILD_F1_POLICY=stream|plain -- f1 tiles fetched past the Infinity Cache or not (default: by the
+ * pyramid's size, stream up to 200 MB); RC_BUILD_NO_DMA=1 -- the kernel without LDS-DMA.
  */
 int rc_build_pyramid(const void* f1, const void* f2, void* vol, const rc_layout* lay,
                      int64_t D, int in_dtype, void* stream);
@@ -297,6 +300,9 @@ int rc_sampler_bwd(const float* coords, int coords_channels, const void* corr_gr
  * rc_lookup_fwd from banded MFMA products, without ever materialising the volume; an odd
  * level's correlations are the means of two of the level below (pooling is linear), so the
  * odd levels of f2 have no copy (f2_offset 0, nothing counted in f2_elems).
+ * Environment (read per call; cache policy only, the results are the same bits):
+ * RC_ALT_F1_POLICY=stream|plain -- rc_alt_fwd fetches f1t past the Infinity Cache or not (default: by
+ * size, stream when f1t + f2t exceed 200 MB, so that f2t stays cached from one lookup to the next).
  */
 typedef struct rc_alt_layout {
   int64_t B, H, W1, W2, D, Dp;

@@ -40,6 +40,7 @@ template <> __device__ __forceinline__ f4v mfma16<rc_bf16>(s8v a, s8v b, f4v c) 
 
 struct alt_dev_layout {
   int B, H, W1, W2, D, Dp, L;
+  int f1_once;  // host side only: picks the kernel that fetches the pixels' own features non-temporally
   int width[RC_MAX_LEVELS];
   int64_t f2_offset[RC_MAX_LEVELS];
 };
@@ -49,6 +50,7 @@ alt_dev_layout to_dev(const rc_alt_layout* a) {
   d.B = (int)a->B; d.H = (int)a->H; d.W1 = (int)a->W1; d.W2 = (int)a->W2;
   d.D = (int)a->D; d.Dp = (int)a->Dp; d.L = a->L;
   for (int i = 0; i < RC_MAX_LEVELS; ++i) { d.width[i] = a->width[i]; d.f2_offset[i] = a->f2_offset[i]; }
+  d.f1_once = 0;
   return d;
 }
 
@@ -133,7 +135,16 @@ __global__ __launch_bounds__(256) void to_fragments_kernel(const T* __restrict__
 // window.h).  The copies of f2 at the odd levels are never read: a third fewer operand bytes per lookup, and the
 // odd levels are means of fp32 sums instead of sums over features pooled and rounded to 16 bits -- closer to
 // the reference, which pools in fp32 (core/corr.py:104).
-template <typename T, int R, int MODE, bool FULL>
+#ifndef RC_LAB_ALT_POLICY  // lab: 1 = f1 fragments non-temporal, 2 = outputs non-temporal, 3 = both
+#define RC_LAB_ALT_POLICY 0
+#endif
+#if RC_LAB_ALT_POLICY & 2
+#define ALT_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define ALT_STORE(ptr, val) (*(ptr) = (val))
+#endif
+
+template <typename T, int R, int MODE, bool FULL, bool F1_ONCE>
 __global__ __launch_bounds__(256) void alt_fwd_kernel(const T* __restrict__ f1t, const T* __restrict__ f2t,
                                                       alt_dev_layout lay, const float* __restrict__ coords,
                                                       int coords_channels, float* __restrict__ out,
@@ -180,10 +191,24 @@ __global__ __launch_bounds__(256) void alt_fwd_kernel(const T* __restrict__ f1t,
   uint4 bfrag[NKC];
   {
     const T* p = f1t + ((int64_t)bh * ((lay.W1 + 15) >> 4) + pb1) * blk_elems + lane * EL;
+    // Both operands together (Middlebury frame: 194 + 243 MB) do not fit the 256 MiB Infinity Cache, and every
+    // lookup reads all of both: with plain loads each evicts the other and everything comes from HBM every time.
+    // f1's fragments have no reader outside their workgroup, so when the two do not fit (F1_ONCE, decided by
+    // the launcher) they are fetched non-temporally and f2 stays in the cache from one lookup to the next:
+    // 100.9 -> 94.1 us.  (Outputs non-temporal as well: 92.5, left plain for their consumer; f2's coarse copy
+    // non-temporal: nothing.)
+    typedef uint32_t alt_u4 __attribute__((ext_vector_type(4)));
 #pragma unroll
     for (int kc = 0; kc < NKC; ++kc) {
-      if (FULL) bfrag[kc] = *reinterpret_cast<const uint4*>(p + kc * 64 * EL);
-      else bfrag[kc] = kc < nkc ? *reinterpret_cast<const uint4*>(p + kc * 64 * EL) : make_uint4(0, 0, 0, 0);
+      if constexpr (F1_ONCE) {  // (a template argument: under a run-time flag the compiler folds the two sets of
+                                // loads into one and drops the policy they do not share)
+        const alt_u4 v = __builtin_nontemporal_load(reinterpret_cast<const alt_u4*>(p + kc * 64 * EL));
+        bfrag[kc] = make_uint4(v[0], v[1], v[2], v[3]);
+      } else if constexpr (FULL) {
+        bfrag[kc] = *reinterpret_cast<const uint4*>(p + kc * 64 * EL);
+      } else {
+        bfrag[kc] = kc < nkc ? *reinterpret_cast<const uint4*>(p + kc * 64 * EL) : make_uint4(0, 0, 0, 0);
+      }
     }
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -217,6 +242,18 @@ __global__ __launch_bounds__(256) void alt_fwd_kernel(const T* __restrict__ f1t,
   uint4 av[NKC], nx[NKC];
   auto fetch = [&](uint4 (&dstv)[NKC], int blk) {
     const T* ap = f2l + blk * blk_elems;
+#if RC_LAB_ALT_POLICY & 4  // lab: the coarse pair's operand (a fifth of f2's bytes) non-temporal
+    if (i == 2) {
+      typedef uint32_t alt_u4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+      for (int kc = 0; kc < NKC; ++kc)
+        if (FULL || kc < nkc) {
+          const alt_u4 v = __builtin_nontemporal_load(reinterpret_cast<const alt_u4*>(ap + kc * 64 * EL));
+          dstv[kc] = make_uint4(v[0], v[1], v[2], v[3]);
+        }
+      return;
+    }
+#endif
 #pragma unroll
     for (int kc = 0; kc < NKC; ++kc)
       if (FULL || kc < nkc) dstv[kc] = *reinterpret_cast<const uint4*>(ap + kc * 64 * EL);
@@ -283,7 +320,7 @@ __global__ __launch_bounds__(256) void alt_fwd_kernel(const T* __restrict__ f1t,
       const int j0 = off_lo + min(max(t0 - base_lo, 0), NS - 2);
       const float v0 = mywin[j0], v1 = mywin[j0 + 1];
       const float s = ((unsigned)t0 < (unsigned)Wlo ? wa * v0 : 0.f) + ((unsigned)(t0 + 1) < (unsigned)Wlo ? wb * v1 : 0.f);
-      if (live && k < NT) orow[(int64_t)(i * NT + k) * HW] = s * scale;
+      if (live && k < NT) ALT_STORE(orow + (int64_t)(i * NT + k) * HW, s * scale);
     }
     if (has_hi) {  // level i + 1: slot pairs (2j, 2j + 1) of the run
       int t0;
@@ -298,7 +335,7 @@ __global__ __launch_bounds__(256) void alt_fwd_kernel(const T* __restrict__ f1t,
       const int j0 = 2 * min(max(t0 - base_hi, 0), NS - 2);
       const float v0 = 0.5f * (mywin[j0] + mywin[j0 + 1]), v1 = 0.5f * (mywin[j0 + 2] + mywin[j0 + 3]);
       const float s = ((unsigned)t0 < (unsigned)Whi ? wa * v0 : 0.f) + ((unsigned)(t0 + 1) < (unsigned)Whi ? wb * v1 : 0.f);
-      if (live && k < NT) orow[(int64_t)((i + 1) * NT + k) * HW] = s * scale;
+      if (live && k < NT) ALT_STORE(orow + (int64_t)((i + 1) * NT + k) * HW, s * scale);
     }
   }
 }
@@ -312,16 +349,20 @@ int launch_alt(const void* f1t, const void* f2t, const alt_dev_layout& d, const 
   RC_REQUIRE(nb < (1ll << 31), RC_EINVAL, "too many pixels");
   const float scale = (float)(1.0 / sqrt((double)d.D));
   const unsigned blocks = (unsigned)nb;
-#define RC_ALT(MODE, FULL)                                                                                  \
-  hipLaunchKernelGGL((alt_fwd_kernel<T, R, MODE, FULL>), dim3(blocks), dim3(256), 0, st, (const T*)f1t,    \
+#define RC_ALT(MODE, FULL, ONCE)                                                                            \
+  hipLaunchKernelGGL((alt_fwd_kernel<T, R, MODE, FULL, ONCE>), dim3(blocks), dim3(256), 0, st, (const T*)f1t, \
                      (const T*)f2t, d, coords, cc, out, scale, bpr, n_rows)
   const bool full = d.Dp == DMAX;
+  // (the streamed-f1 variant exists for full-depth features only: operands too large for the cache at fewer
+  // channels take the plain loads)
   if (mode == RC_COORD_EXACT) {
-    if (full) RC_ALT(RC_COORD_EXACT, true);
-    else RC_ALT(RC_COORD_EXACT, false);
+    if (full && d.f1_once) RC_ALT(RC_COORD_EXACT, true, true);
+    else if (full) RC_ALT(RC_COORD_EXACT, true, false);
+    else RC_ALT(RC_COORD_EXACT, false, false);
   } else {
-    if (full) RC_ALT(RC_COORD_GRIDSAMPLE, true);
-    else RC_ALT(RC_COORD_GRIDSAMPLE, false);
+    if (full && d.f1_once) RC_ALT(RC_COORD_GRIDSAMPLE, true, true);
+    else if (full) RC_ALT(RC_COORD_GRIDSAMPLE, true, false);
+    else RC_ALT(RC_COORD_GRIDSAMPLE, false, false);
   }
 #undef RC_ALT
   return rc_check_launch("rc_alt_fwd");
@@ -424,7 +465,11 @@ extern "C" int rc_alt_fwd(const void* f1t, const void* f2t, const rc_alt_layout*
   if (coord_mode == RC_COORD_GRIDSAMPLE)
     RC_REQUIRE(lay->width[lay->L - 1] >= 2, RC_EINVAL, "grid_sample coordinates need every level at least 2 wide");
   RC_REQUIRE((uintptr_t)f1t % 16 == 0 && (uintptr_t)f2t % 16 == 0, RC_EINVAL, "working copies must be 16-byte aligned");
-  const alt_dev_layout d = to_dev(lay);
+  alt_dev_layout d = to_dev(lay);
+  // operands that cannot both stay in the 256 MiB Infinity Cache between lookups: f1 is streamed past it
+  const int64_t esize = in_dtype == RC_F32 ? 4 : 2;
+  const char* policy = getenv("RC_ALT_F1_POLICY");  // "stream" / "plain": overrides the size rule (tests, measurements)
+  d.f1_once = policy ? !strcmp(policy, "stream") : (lay->f1_elems + lay->f2_elems) * esize > (200ll << 20);
   hipStream_t st = (hipStream_t)stream;
   switch (in_dtype) {
     case RC_F32: return dispatch_alt<float>(f1t, f2t, d, coords, coords_channels, out, radius, coord_mode, st);

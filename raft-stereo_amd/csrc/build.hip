@@ -17,6 +17,7 @@
 
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 
 // Ablation switches for tools/lab_build.hip only (the library is built with 0): 1 = no pyramid stores,
@@ -1039,7 +1040,9 @@ int launch_build(const void* f1, const void* f2, void* vol, const rc_layout* lay
     for (int i = 0; i < lay->L; i += 2) dma = dma && d.bias[i] <= 3 * (lay->widthp[i] / 8);
     // a pyramid that can stay in the 256 MiB Infinity Cache for the lookups is worth protecting from the f1 stream
     // (see glds16); a larger one is not, and there the non-temporal f1 costs the build 8 % (64 KITTI pairs)
-    const bool f1_once = lay->total * (int64_t)sizeof(T) <= (200ll << 20) && !getenv("RC_BUILD_F1_PLAIN");
+    // (RC_BUILD_F1_POLICY=stream|plain overrides the size rule: tests, measurements)
+    const char* policy = getenv("RC_BUILD_F1_POLICY");
+    const bool f1_once = policy ? !strcmp(policy, "stream") : lay->total * (int64_t)sizeof(T) <= (200ll << 20);
     if (dma && f1_once)
       hipLaunchKernelGGL((build16g_kernel<T, true>), dim3((unsigned)blocks), dim3(BT16), 2 * G_BUF, st, (const T*)f1,
                          (const T*)f2, (T*)vol, d, scale, n_tiles, n_rows);

@@ -131,6 +131,31 @@ def test_alt_equals_reg_every_level_count(R, dtype, levels, radius, shape):
         assert rel(alt, reg.cpu().numpy()) < (2e-5 if dtype == torch.float32 else 2e-3)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("radius", [1, 4, 6])
+def test_alt_streamed_f1_is_the_same_lookup(R, dtype, radius, monkeypatch):
+    """Operands too large for the Infinity Cache pick the kernel that fetches f1's fragments past the cache
+    (rc_alt_fwd's size rule; full-depth features only).  A cache policy, not arithmetic: forced on a small
+    frame it returns the plain kernel's bits, both coordinate modes.  (The size rule itself is what
+    test_middlebury_full_size_alt_and_row_slabs runs: its full frame streams, its slabs do not.)"""
+    B, D, H, W1, W2, L = 2, 256, 3, 75, 83, 4
+    gen = torch.Generator(device="cuda").manual_seed(radius)
+    f1 = torch.randn((B, D, H, W1), generator=gen, device="cuda").to(dtype)
+    f2 = torch.randn((B, D, H, W2), generator=gen, device="cuda").to(dtype)
+    coords = torch.zeros((B, 2, H, W1), device="cuda")
+    coords[:, 0] = torch.rand((B, H, W1), generator=gen, device="cuda") * (W2 + 30) - 15
+    for mode in ("exact", "gridsample"):
+        alt = R.AltCorrBlock1DHip(f1, f2, num_levels=L, radius=radius, coord_mode=mode)
+        got = {}
+        for policy in ("plain", "stream"):
+            monkeypatch.setenv("RC_ALT_F1_POLICY", policy)
+            with torch.no_grad():
+                got[policy] = alt(coords)
+        monkeypatch.delenv("RC_ALT_F1_POLICY")
+        assert float(got["plain"].abs().max()) > 0
+        assert torch.equal(got["plain"], got["stream"]), mode
+
+
 @pytest.mark.parametrize("case", GOLDEN_CASES)
 def test_alt_backward_fp32_matches_reference_autograd(R, golden, case):
     """alt_hip is the same function of the feature maps as reg, so the reference's autograd
@@ -194,6 +219,32 @@ def test_build_mfma_equals_naive_kernel(R, dtype, shape):
         a = blk.dense_level(i, volume=ref).float()
         b = blk.dense_level(i).float()
         assert torch.equal(a, b), f"level {i} differs: max {float((a - b).abs().max())}"
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 256, 5, 312, 312), (1, 256, 3, 136, 200), (1, 128, 2, 752, 752)])
+def test_build_cache_policies_are_the_same_pyramid(R, dtype, shape, monkeypatch):
+    """rc_build_pyramid picks by the pyramid's size whether f1's tiles are fetched past the Infinity Cache
+    (up to 200 MB: yes, so the pyramid is still cached for the lookups; 64 KITTI pairs: no).  Only the bench's
+    largest workload reaches the second kernel by size, so it is forced here: same bits as the first, on
+    real-valued data, and both the same bits as the kernel without LDS-DMA."""
+    B, D, H, W1, W2 = shape
+    gen = torch.Generator(device="cuda").manual_seed(23)
+    f1 = torch.randn((B, D, H, W1), generator=gen, device="cuda").to(dtype)
+    f2 = torch.randn((B, D, H, W2), generator=gen, device="cuda").to(dtype)
+    vols = {}
+    for name, env in (("stream", {"RC_BUILD_F1_POLICY": "stream"}), ("plain", {"RC_BUILD_F1_POLICY": "plain"}),
+                      ("no_dma", {"RC_BUILD_NO_DMA": "1"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        blk = R.CorrBlock1DHip(f1, f2, num_levels=4, radius=4)
+        vols[name] = [blk.dense_level(i).clone() for i in range(4)]
+        for k in env:
+            monkeypatch.delenv(k)
+    for i in range(4):
+        assert float(vols["stream"][i].float().abs().max()) > 0
+        assert torch.equal(vols["stream"][i], vols["plain"][i]), f"level {i}: stream / plain"
+        assert torch.equal(vols["stream"][i], vols["no_dma"][i]), f"level {i}: LDS-DMA / round 2's kernel"
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
