@@ -227,14 +227,16 @@ def test_build_cache_policies_are_the_same_pyramid(R, dtype, shape, monkeypatch)
     """rc_build_pyramid picks by the pyramid's size whether f1's tiles are fetched past the Infinity Cache
     (up to 200 MB: yes, so the pyramid is still cached for the lookups; 64 KITTI pairs: no).  Only the bench's
     largest workload reaches the second kernel by size, so it is forced here: same bits as the first, on
-    real-valued data, and both the same bits as the kernel without LDS-DMA."""
+    real-valued data, and both the same bits as the kernel without LDS-DMA -- and as either order in which the
+    image rows are dealt to the XCDs (RC_BUILD_ROW_ORDER)."""
     B, D, H, W1, W2 = shape
     gen = torch.Generator(device="cuda").manual_seed(23)
     f1 = torch.randn((B, D, H, W1), generator=gen, device="cuda").to(dtype)
     f2 = torch.randn((B, D, H, W2), generator=gen, device="cuda").to(dtype)
     vols = {}
     for name, env in (("stream", {"RC_BUILD_F1_POLICY": "stream"}), ("plain", {"RC_BUILD_F1_POLICY": "plain"}),
-                      ("no_dma", {"RC_BUILD_NO_DMA": "1"})):
+                      ("no_dma", {"RC_BUILD_NO_DMA": "1"}), ("interleaved", {"RC_BUILD_ROW_ORDER": "interleaved"}),
+                      ("no_dma_interleaved", {"RC_BUILD_NO_DMA": "1", "RC_BUILD_ROW_ORDER": "interleaved"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         blk = R.CorrBlock1DHip(f1, f2, num_levels=4, radius=4)
@@ -245,6 +247,9 @@ def test_build_cache_policies_are_the_same_pyramid(R, dtype, shape, monkeypatch)
         assert float(vols["stream"][i].float().abs().max()) > 0
         assert torch.equal(vols["stream"][i], vols["plain"][i]), f"level {i}: stream / plain"
         assert torch.equal(vols["stream"][i], vols["no_dma"][i]), f"level {i}: LDS-DMA / round 2's kernel"
+        # which XCD gets which image rows (B*H = 10, 3, 2 rows: not multiples of 8) changes no bit either
+        assert torch.equal(vols["stream"][i], vols["interleaved"][i]), f"level {i}: row order"
+        assert torch.equal(vols["stream"][i], vols["no_dma_interleaved"][i]), f"level {i}: row order, round 2's kernel"
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
