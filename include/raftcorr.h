@@ -304,6 +304,7 @@ int rc_sampler_bwd(const float* coords, int coords_channels, const void* corr_gr
  * Environment (read per call; cache policy only, the results are the same bits):
  * RC_ALT_F1_POLICY=stream|plain -- rc_alt_fwd fetches f1t past the Infinity Cache or not (default: by
  * size, stream when f1t + f2t exceed 200 MB, so that f2t stays cached from one lookup to the next).
+ * RC_ALT_PREPARE=elements -- rc_alt_prepare's kernel for arbitrary widths also where the 16-byte kernel applies.
  */
 typedef struct rc_alt_layout {
   int64_t B, H, W1, W2, D, Dp;

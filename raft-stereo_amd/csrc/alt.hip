@@ -126,6 +126,94 @@ __global__ __launch_bounds__(256) void to_fragments_kernel(const T* __restrict__
   }
 }
 
+// The same working copies for 16-bit features whose rows are whole 16-byte segments (W % 8 == 0, 16-byte aligned):
+// 16-byte loads (a wave fetches 4 channels x 256 contiguous bytes per instruction instead of 128 bytes of 2-byte
+// elements), a 16-bit tile in LDS, and gfx950's transposing LDS read (ds_read_b64_tr_b16: a group of 16 lanes reads
+// 4 channel rows x 16 positions and every lane receives the 4 channels of its own position), so a fragment piece
+// costs 2 LDS reads instead of 8 and no conversion.  Level 2 is pooled in registers, in fp32 and in the order of
+// the element kernel's tree (means of pairs, then means of those, rounded once): the same bits.
+constexpr int TF_P0 = 256 + 32;  // bytes per channel row of the level-0 tile (128 positions); + 32: the 4 rows of a
+constexpr int TF_P2 = 64 + 32;   // transposing read start 8 banks apart.  Level 2: 32 positions.
+
+template <typename T>
+__global__ __launch_bounds__(256) void to_fragments16_kernel(const T* __restrict__ src, T* __restrict__ dst,
+                                                             int D, int Dp, int H, int W, frag_levels lv) {
+  static_assert(sizeof(T) == 2, "16-bit features");
+  typedef short s4v __attribute__((ext_vector_type(4)));
+  typedef s4v __attribute__((address_space(3))) * lds_s4p;
+  __shared__ __attribute__((aligned(16))) unsigned char t0[64 * TF_P0];
+  __shared__ __attribute__((aligned(16))) unsigned char t2[64 * TF_P2];
+  const int nkc = Dp / 32;
+  const int w0 = blockIdx.x * 128, d0 = blockIdx.y * 64;
+  const int bh = blockIdx.z, b = bh / H, h = bh - b * H;
+  const bool pooled = lv.nlev >= 3;  // level 2 is wanted (level 1 is only a step on the way)
+  {
+    const int seg = threadIdx.x & 15, cr = threadIdx.x >> 4;  // 8 positions of one channel; 16 channels per pass
+    const int w = w0 + seg * 8;
+    const bool in_w = w < W;  // whole segments: W % 8 == 0
+    const T* col = src + ((int64_t)b * D * H + h) * W + (in_w ? w : 0);
+    const int64_t dstride = (int64_t)H * W;
+    uint4 v[4];
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass)  // clamped, not predicated; zeroed below
+      v[pass] = *reinterpret_cast<const uint4*>(col + (int64_t)min(d0 + pass * 16 + cr, D - 1) * dstride);
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int dd = pass * 16 + cr;
+      if (!in_w || d0 + dd >= D) v[pass] = make_uint4(0, 0, 0, 0);
+      *reinterpret_cast<uint4*>(t0 + dd * TF_P0 + seg * 16) = v[pass];
+      if (pooled) {
+        const uint32_t x[4] = {v[pass].x, v[pass].y, v[pass].z, v[pass].w};
+        float l1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          T e[2];
+          __builtin_memcpy(e, &x[j], 4);
+          l1[j] = 0.5f * (rc_to_float(e[0]) + rc_to_float(e[1]));
+        }
+        const T l2[2] = {rc_from_float<T>(0.5f * (l1[0] + l1[1])), rc_from_float<T>(0.5f * (l1[2] + l1[3]))};
+        uint32_t packed;
+        __builtin_memcpy(&packed, l2, 4);
+        *reinterpret_cast<uint32_t*>(t2 + dd * TF_P2 + seg * 4) = packed;
+      }
+    }
+  }
+  __syncthreads();
+  // one 16-byte fragment piece per thread and step: lane (g, li) of a wave = channels 8 g .. 8 g + 7 of position li
+  // of one block; (block, channel chunk) are wave-uniform, so the bounds tests below are, too
+  const int li = threadIdx.x & 15, g = (threadIdx.x >> 4) & 3;
+  const int lane_off = (8 * g + (li >> 2));  // channel row this lane addresses in a transposing read
+  auto piece = [&](const unsigned char* tile, int pitch, int kcl, int blk) {
+    const unsigned char* a = tile + (kcl * 32 + lane_off) * pitch + blk * 32 + (li & 3) * 8;
+    const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)a);
+    const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(a + 4 * pitch));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  if (lv.offset[0] >= 0) {
+    const int nblk = (lv.width[0] + 15) >> 4;
+    T* base = dst + lv.offset[0];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int f = (int)threadIdx.x + 256 * s;
+      const int kcl = (f >> 6) & 1, blk = f >> 7;
+      const int pb = (w0 >> 4) + blk, kc = d0 / 32 + kcl;
+      const s8v v = piece(t0, TF_P0, kcl, blk);
+      if (pb < nblk && kc < nkc)
+        *reinterpret_cast<s8v*>(base + ((((int64_t)bh * nblk + pb) * nkc + kc) * 64 + g * 16 + li) * 8) = v;
+    }
+  }
+  if (pooled && lv.offset[2] >= 0) {
+    const int nblk = (lv.width[2] + 15) >> 4;
+    T* base = dst + lv.offset[2];
+    const int f = (int)threadIdx.x;
+    const int kcl = (f >> 6) & 1, blk = f >> 7;
+    const int pb = (w0 >> 6) + blk, kc = d0 / 32 + kcl;
+    const s8v v = piece(t2, TF_P2, kcl, blk);
+    if (pb < nblk && kc < nkc)
+      *reinterpret_cast<s8v*>(base + ((((int64_t)bh * nblk + pb) * nkc + kc) * 64 + g * 16 + li) * 8) = v;
+  }
+}
+
 // FULL: Dp == DMAX, every operand load unconditional (the real model's D = 256).
 // A wave serves a PAIR of levels (i, i + 1), i even, of 16 pixels: pooling is linear, so the correlation with the
 // pooled right image is the mean of two correlations one level down,
@@ -399,8 +487,20 @@ int run_prepare(const void* f1, const void* f2, void* f1t, void* f2t, const rc_a
   frag_levels one = {};
   one.nlev = 1;
   one.width[0] = (int)a->W1;
-  hipLaunchKernelGGL((to_fragments_kernel<T>), dim3((unsigned)((a->W1 + 127) / 128), (Dp + 63) / 64, BH), dim3(256),
-                     0, st, (const T*)f1, (T*)f1t, D, Dp, H, (int)a->W1, one);
+  // 16-bit rows of whole, aligned 16-byte segments: the vector kernel (RC_ALT_PREPARE=elements: the other one)
+  const char* how = getenv("RC_ALT_PREPARE");
+  const bool elements = sizeof(T) != 2 || (how && !strcmp(how, "elements"));
+  auto launch = [&](const void* src, void* dst, int W, const frag_levels& lv) {
+    const dim3 grid((unsigned)((W + 127) / 128), (Dp + 63) / 64, BH);
+    if constexpr (sizeof(T) == 2) {
+      if (!elements && W % 8 == 0 && (uintptr_t)src % 16 == 0 && (uintptr_t)dst % 16 == 0) {
+        hipLaunchKernelGGL((to_fragments16_kernel<T>), grid, dim3(256), 0, st, (const T*)src, (T*)dst, D, Dp, H, W, lv);
+        return;
+      }
+    }
+    hipLaunchKernelGGL((to_fragments_kernel<T>), grid, dim3(256), 0, st, (const T*)src, (T*)dst, D, Dp, H, W, lv);
+  };
+  launch(f1, f1t, (int)a->W1, one);
   int rc = rc_check_launch("rc_alt_prepare(f1)");
   if (rc) return rc;
   frag_levels all = {};
@@ -409,8 +509,7 @@ int run_prepare(const void* f1, const void* f2, void* f1t, void* f2t, const rc_a
     all.width[i] = a->width[i];
     all.offset[i] = (i & 1) ? -1 : a->f2_offset[i];
   }
-  hipLaunchKernelGGL((to_fragments_kernel<T>), dim3((unsigned)((a->W2 + 127) / 128), (Dp + 63) / 64, BH), dim3(256),
-                     0, st, (const T*)f2, (T*)f2t, D, Dp, H, (int)a->W2, all);
+  launch(f2, f2t, (int)a->W2, all);
   return rc_check_launch("rc_alt_prepare(f2)");
 }
 

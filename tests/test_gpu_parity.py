@@ -156,6 +156,34 @@ def test_alt_streamed_f1_is_the_same_lookup(R, dtype, radius, monkeypatch):
         assert torch.equal(got["plain"], got["stream"]), mode
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("levels,shape", [(4, (2, 256, 3, 752, 752)), (4, (1, 96, 2, 72, 200)), (3, (1, 64, 2, 136, 40)),
+                                          (2, (1, 32, 1, 8, 16)), (1, (1, 160, 2, 264, 120)), (4, (1, 256, 2, 184, 88))])
+def test_alt_prepare_vector_kernel_writes_the_same_working_copies(R, dtype, levels, shape, monkeypatch):
+    """rc_alt_prepare has two kernels for 16-bit features: 2-byte loads and an fp32 tile (any width), and 16-byte
+    loads with the transposing LDS read (rows of whole 16-byte segments).  Same working copies, every element of
+    them (padding positions and channels included), so every lookup is the same whichever ran."""
+    B, D, H, W1, W2 = shape
+    gen = torch.Generator(device="cuda").manual_seed(levels)
+    f1 = torch.randn((B, D, H, W1), generator=gen, device="cuda").to(dtype)
+    f2 = torch.randn((B, D, H, W2), generator=gen, device="cuda").to(dtype)
+    got = {}
+    for how in ("elements", "vector"):
+        monkeypatch.setenv("RC_ALT_PREPARE", how)
+        blk = R.AltCorrBlock1DHip(f1, f2, num_levels=levels, radius=2)
+        # poison first: an element neither kernel writes would show
+        blk.f1t.view(torch.int16).fill_(0x7bff)
+        blk.f2t.view(torch.int16).fill_(0x7bff)
+        from raft_stereo_amd._lib import lib, check
+        check(lib.rc_alt_prepare(f1.data_ptr(), f2.data_ptr(), blk.f1t.data_ptr(), blk.f2t.data_ptr(), blk.layout,
+                                 blk.in_dtype, torch.cuda.current_stream().cuda_stream), "rc_alt_prepare")
+        got[how] = (blk.f1t.view(torch.int16).clone(), blk.f2t.view(torch.int16).clone())
+    monkeypatch.delenv("RC_ALT_PREPARE")
+    assert int((got["vector"][0] != 0).sum()) > 0
+    assert torch.equal(got["elements"][0], got["vector"][0]), "f1t"
+    assert torch.equal(got["elements"][1], got["vector"][1]), "f2t"
+
+
 @pytest.mark.parametrize("case", GOLDEN_CASES)
 def test_alt_backward_fp32_matches_reference_autograd(R, golden, case):
     """alt_hip is the same function of the feature maps as reg, so the reference's autograd
