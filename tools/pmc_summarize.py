@@ -16,7 +16,7 @@ csv.field_size_limit(1 << 30)
 
 
 OURS = ("lookup_fwd_kernel_vt", "lookup_convc1_kernel", "convc1_pack_kernel", "adjoint_dense_kernel", "lookup_fwd_kernel", "lookup_bwd_kernel", "lookup_adjoint_kernel", "build16g_kernel", "build16_kernel", "build_kernel", "unskew_fold_kernel",
-        "gemm_nt_kernel", "gemm_rows_kernel", "alt_fwd_kernel", "to_fragments_kernel", "sampler_fwd_kernel", "sampler_bwd_kernel",
+        "gemm_nt_kernel", "gemm_rows_kernel", "alt_fwd_kernel", "to_fragments_kernel", "to_fragments16_kernel", "sampler_fwd_kernel", "sampler_bwd_kernel",
         "naive_corr_kernel", "naive_pool_kernel", "gru_gate_r_kernel", "gru_update_kernel", "gru_gate_r_bwd_kernel",
         "gru_update_bwd_kernel", "upsample_kernel", "upsample_bwd_kernel", "upsample_bwd_flow_kernel",
         "convc1_bwd_taps_mfma_kernel", "convc1_bwd_weight_mfma_kernel", "convc1_bwd_taps_kernel",
