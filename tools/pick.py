@@ -1,3 +1,4 @@
+"""Filter: `python bench.py ... | python3 tools/pick.py` prints the few fields of the JSON line that an A/B run compares."""
 import sys, json
 for line in sys.stdin:
     line=line.strip()
