@@ -137,6 +137,8 @@ int rc_grad_pyramid_layout(int64_t B, int64_t H, int64_t W1, int64_t W2, int L, 
  * RC_BUILD_F1_POLICY=stream|plain -- f1 tiles fetched past the Infinity Cache or not (default: by the
  * pyramid's size, stream up to 200 MB); RC_BUILD_NO_DMA=1 -- the kernel without LDS-DMA;
  * RC_BUILD_ROW_ORDER=contiguous|interleaved -- image rows of one XCD (default: contiguous for 16-bit features).
+ * RC_BUILD_F1_TILES=line|row -- f1 tiles start on 128-byte lines of memory or at the row's first column
+ *   (default: line where the k planes are whole lines apart and the rows are not).
  */
 int rc_build_pyramid(const void* f1, const void* f2, void* vol, const rc_layout* lay,
                      int64_t D, int in_dtype, void* stream);

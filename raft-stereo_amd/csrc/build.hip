@@ -513,7 +513,7 @@ __device__ __forceinline__ void dma_tile(const T* rowbase, int64_t kstride, int 
   const int kr = lane >> 3;
   const int ls = (lane & 7) ^ (((kr >> 1) & 3) << 1);  // the logical segment this lane's slot holds
   int col = n0 + ls * 8;
-  col = col >= W ? 0 : col;
+  col = (unsigned)col >= (unsigned)W ? 0 : col;  // (also the columns before the row of a shifted f1 tile)
   const T* src = rowbase + (int64_t)(wave * 8 + kr) * kstride + col;
 #pragma unroll
   for (int p = 0; p < 4; ++p)
@@ -569,7 +569,7 @@ __device__ __forceinline__ void slab_store16(const out_slab& sl, uint32_t blk_by
   t = min(t, t - sl.nb);
   uint32_t off = __umul24(t, blk_bytes) + (uint32_t)col * 16u;
   asm volatile("" : "+v"(off));  // computed for every lane: the select stays a v_cndmask
-  off = (col < W1 && (uint32_t)G < sl.nb) ? off : sl.bytes;
+  off = ((uint32_t)col < (uint32_t)W1 && (uint32_t)G < sl.nb) ? off : sl.bytes;  // (col < 0: shifted first tile)
   const u4v v = {a, b, c, d};
   if constexpr (RC_LAB_ABLATE & 1) {
     asm volatile("" ::"v"(v), "v"(off));
@@ -614,7 +614,8 @@ __device__ __forceinline__ void epilogue16_g(const f4v (&acc)[2][2], float scale
 template <typename T, bool F1_ONCE>
 __global__ __launch_bounds__(BT16, 4) void build16g_kernel(const T* __restrict__ f1, const T* __restrict__ f2,
                                                            T* __restrict__ vol, rc_dev_layout lay, float scale,
-                                                           int n_tiles, int n_rows, int rows_per_xcd) {
+                                                           int n_tiles, int n_rows, int rows_per_xcd,
+                                                           int line_tiles) {
   using C = build_cfg<T>;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   // XCD-aware mapping: the tiles of an image row on one XCD as in build16_kernel, and (rows_per_xcd > 0) every XCD
@@ -626,17 +627,25 @@ __global__ __launch_bounds__(BT16, 4) void build16g_kernel(const T* __restrict__
   const int tile = j % n_tiles;
   if (row >= n_rows) return;
   const int b = row / lay.H, h = row - b * lay.H;
-  const int c0 = tile * TM;
   const int W1 = lay.W1, W2 = lay.W2, L = lay.L;
   constexpr int D = KMAX;
+  const T* f1row = f1 + ((int64_t)b * D * lay.H + h) * W1;
+  const T* f2row = f2 + ((int64_t)b * D * lay.H + h) * W2;
+  // line_tiles (the k planes are a whole number of 128-byte lines apart): the tiles of f1 start on 128-byte lines
+  // of memory instead of at the row's first column -- a row of 624 bytes starts anywhere in a line, a 256-byte
+  // piece of it then straddles three lines, and the two it shares with the neighbouring tiles were fetched twice
+  // (the f1 stream is non-temporal: a line does not wait in the L2 for its second reader).  The first tile is
+  // narrower by the row's offset in its line, the launcher's tile count covers the widest case, and a tile that
+  // starts past the row has nothing to do.
+  const int shift = line_tiles ? (int)((reinterpret_cast<uintptr_t>(f1row) >> 1) & 63) : 0;  // columns, multiple of 8
+  const int c0 = tile * TM - shift;
+  if (c0 >= W1) return;
 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int cg = wave & 3, rh = wave >> 2;  // column group (32 columns), half of the chunk's rows
   const int cw = c0 + cg * 32;
-  const bool active = cw < W1;  // wave-uniform: a wave past the row end only helps with the staging
+  const bool active = cw < W1 && cw + 32 > 0;  // wave-uniform: a wave outside the row only helps with the staging
 
-  const T* f1row = f1 + ((int64_t)b * D * lay.H + h) * W1;
-  const T* f2row = f2 + ((int64_t)b * D * lay.H + h) * W2;
   const int64_t ks1 = (int64_t)lay.H * W1, ks2 = (int64_t)lay.H * W2;
   const int n_chunks = (W2 + C::TN - 1) / C::TN;
   typedef unsigned char __attribute__((address_space(3))) * lds_p;
@@ -1052,12 +1061,21 @@ int launch_build(const void* f1, const void* f2, void* vol, const rc_layout* lay
     // (RC_BUILD_F1_POLICY=stream|plain overrides the size rule: tests, measurements)
     const char* policy = getenv("RC_BUILD_F1_POLICY");
     const bool f1_once = policy ? !strcmp(policy, "stream") : lay->total * (int64_t)sizeof(T) <= (200ll << 20);
+    // f1 tiles on the 128-byte lines of memory (see the kernel) where that means the same for every k plane and
+    // the rows do not start on lines anyway; one more tile per row if the widest shifted row needs it
+    const char* tiles = getenv("RC_BUILD_F1_TILES");  // "row" / "line": overrides (tests, measurements)
+    const bool planes_on_lines = ((int64_t)lay->H * lay->W1 * (int64_t)sizeof(T)) % 128 == 0;
+    const bool rows_on_lines = (lay->W1 * (int64_t)sizeof(T)) % 128 == 0 && ((uintptr_t)f1) % 128 == 0;
+    const int line_tiles = tiles ? !strcmp(tiles, "line") : (planes_on_lines && !rows_on_lines);
+    const int n_tiles_g = line_tiles ? (int)((lay->W1 + 56 + TM - 1) / TM) : n_tiles;
+    const int64_t blocks_g = (int64_t)((n_rows + 7) / 8) * 8 * n_tiles_g;
+    RC_REQUIRE(blocks_g < (1ll << 31), RC_EINVAL, "grid too large");
     if (dma && f1_once)
-      hipLaunchKernelGGL((build16g_kernel<T, true>), dim3((unsigned)blocks), dim3(BT16), 2 * G_BUF, st, (const T*)f1,
-                         (const T*)f2, (T*)vol, d, scale, n_tiles, n_rows, rows_per_xcd);
+      hipLaunchKernelGGL((build16g_kernel<T, true>), dim3((unsigned)blocks_g), dim3(BT16), 2 * G_BUF, st, (const T*)f1,
+                         (const T*)f2, (T*)vol, d, scale, n_tiles_g, n_rows, rows_per_xcd, line_tiles);
     else if (dma)
-      hipLaunchKernelGGL((build16g_kernel<T, false>), dim3((unsigned)blocks), dim3(BT16), 2 * G_BUF, st, (const T*)f1,
-                         (const T*)f2, (T*)vol, d, scale, n_tiles, n_rows, rows_per_xcd);
+      hipLaunchKernelGGL((build16g_kernel<T, false>), dim3((unsigned)blocks_g), dim3(BT16), 2 * G_BUF, st, (const T*)f1,
+                         (const T*)f2, (T*)vol, d, scale, n_tiles_g, n_rows, rows_per_xcd, line_tiles);
     else if (fast && whole) RC_LAUNCH_BUILD16(2);
     else if (fast) RC_LAUNCH_BUILD16(1);
     else RC_LAUNCH_BUILD16(0);

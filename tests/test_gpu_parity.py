@@ -250,7 +250,8 @@ def test_build_mfma_equals_naive_kernel(R, dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("shape", [(2, 256, 5, 312, 312), (1, 256, 3, 136, 200), (1, 128, 2, 752, 752)])
+@pytest.mark.parametrize("shape", [(2, 256, 5, 312, 312), (1, 256, 3, 136, 200), (1, 128, 2, 752, 752),
+                                   (1, 256, 4, 384, 96), (1, 256, 16, 72, 312)])
 def test_build_cache_policies_are_the_same_pyramid(R, dtype, shape, monkeypatch):
     """rc_build_pyramid picks by the pyramid's size whether f1's tiles are fetched past the Infinity Cache
     (up to 200 MB: yes, so the pyramid is still cached for the lookups; 64 KITTI pairs: no).  Only the bench's
@@ -264,7 +265,8 @@ def test_build_cache_policies_are_the_same_pyramid(R, dtype, shape, monkeypatch)
     vols = {}
     for name, env in (("stream", {"RC_BUILD_F1_POLICY": "stream"}), ("plain", {"RC_BUILD_F1_POLICY": "plain"}),
                       ("no_dma", {"RC_BUILD_NO_DMA": "1"}), ("interleaved", {"RC_BUILD_ROW_ORDER": "interleaved"}),
-                      ("no_dma_interleaved", {"RC_BUILD_NO_DMA": "1", "RC_BUILD_ROW_ORDER": "interleaved"})):
+                      ("no_dma_interleaved", {"RC_BUILD_NO_DMA": "1", "RC_BUILD_ROW_ORDER": "interleaved"}),
+                      ("line_tiles", {"RC_BUILD_F1_TILES": "line"}), ("row_tiles", {"RC_BUILD_F1_TILES": "row"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         blk = R.CorrBlock1DHip(f1, f2, num_levels=4, radius=4)
@@ -278,6 +280,9 @@ def test_build_cache_policies_are_the_same_pyramid(R, dtype, shape, monkeypatch)
         # which XCD gets which image rows (B*H = 10, 3, 2 rows: not multiples of 8) changes no bit either
         assert torch.equal(vols["stream"][i], vols["interleaved"][i]), f"level {i}: row order"
         assert torch.equal(vols["stream"][i], vols["no_dma_interleaved"][i]), f"level {i}: row order, round 2's kernel"
+        # f1 tiles that start on 128-byte lines of memory (first tile narrower, columns before the row masked)
+        assert torch.equal(vols["line_tiles"][i], vols["row_tiles"][i]), f"level {i}: f1 tiles on lines / on the row"
+        assert torch.equal(vols["line_tiles"][i], vols["no_dma"][i]), f"level {i}: f1 tiles on lines / round 2's kernel"
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
