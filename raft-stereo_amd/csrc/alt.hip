@@ -137,15 +137,23 @@ constexpr int TF_P2 = 64 + 32;   // transposing read start 8 banks apart.  Level
 
 template <typename T>
 __global__ __launch_bounds__(256) void to_fragments16_kernel(const T* __restrict__ src, T* __restrict__ dst,
-                                                             int D, int Dp, int H, int W, frag_levels lv) {
+                                                             int D, int Dp, int H, int W, frag_levels lv,
+                                                             int n_rows, int rows_per_xcd) {
   static_assert(sizeof(T) == 2, "16-bit features");
   typedef short s4v __attribute__((ext_vector_type(4)));
   typedef s4v __attribute__((address_space(3))) * lds_s4p;
   __shared__ __attribute__((aligned(16))) unsigned char t0[64 * TF_P0];
   __shared__ __attribute__((aligned(16))) unsigned char t2[64 * TF_P2];
   const int nkc = Dp / 32;
-  const int w0 = blockIdx.x * 128, d0 = blockIdx.y * 64;
-  const int bh = blockIdx.z, b = bh / H, h = bh - b * H;
+  // one-dimensional grid, XCD-aware: an XCD works through a run of consecutive image rows, and through the tiles
+  // of one row one after the other -- a tile's 256-byte pieces do not start on 128-byte lines, and the lines it
+  // shares with its neighbours (and the row with the next row) then meet in one L2
+  const int xt = (W + 127) >> 7, dt = (Dp + 63) >> 6, per_row = xt * dt;
+  const int slot = blockIdx.x >> 3, rl = slot / per_row, t = slot - rl * per_row;
+  const int bh = (blockIdx.x & 7) * rows_per_xcd + rl;
+  if (bh >= n_rows) return;
+  const int w0 = (t % xt) * 128, d0 = (t / xt) * 64;
+  const int b = bh / H, h = bh - b * H;
   const bool pooled = lv.nlev >= 3;  // level 2 is wanted (level 1 is only a step on the way)
   {
     const int seg = threadIdx.x & 15, cr = threadIdx.x >> 4;  // 8 positions of one channel; 16 channels per pass
@@ -494,8 +502,13 @@ int run_prepare(const void* f1, const void* f2, void* f1t, void* f2t, const rc_a
     const dim3 grid((unsigned)((W + 127) / 128), (Dp + 63) / 64, BH);
     if constexpr (sizeof(T) == 2) {
       if (!elements && W % 8 == 0 && (uintptr_t)src % 16 == 0 && (uintptr_t)dst % 16 == 0) {
-        hipLaunchKernelGGL((to_fragments16_kernel<T>), grid, dim3(256), 0, st, (const T*)src, (T*)dst, D, Dp, H, W, lv);
-        return;
+        const int rows_per_xcd = ((int)BH + 7) / 8;
+        const int64_t nb = (int64_t)rows_per_xcd * 8 * grid.x * grid.y;
+        if (nb < (1ll << 31)) {
+          hipLaunchKernelGGL((to_fragments16_kernel<T>), dim3((unsigned)nb), dim3(256), 0, st, (const T*)src, (T*)dst, D,
+                             Dp, H, W, lv, (int)BH, rows_per_xcd);
+          return;
+        }
       }
     }
     hipLaunchKernelGGL((to_fragments_kernel<T>), grid, dim3(256), 0, st, (const T*)src, (T*)dst, D, Dp, H, W, lv);
