@@ -14,6 +14,8 @@
 #include "rc_common.h"
 
 #include <math.h>
+#include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 
 namespace {
@@ -124,7 +126,8 @@ __device__ __forceinline__ u4v load_feat(const T* __restrict__ row, int k, int K
 template <typename T, bool TRANS, bool VEC>
 __global__ __launch_bounds__(GT) void gemm_rows_kernel(const T* __restrict__ feat, const T* __restrict__ dC,
                                                        T* __restrict__ out, int M, int N, int K, int H, int W1,
-                                                       int ldc, int n_slabs, int n_mgroups, int n_rows) {
+                                                       int ldc, int n_slabs, int n_mgroups, int n_rows,
+                                                       int rows_per_xcd) {
   constexpr bool vec = VEC;  // feature rows on 4-byte boundaries and at least one 16-byte piece long
   using C = gemm_cfg<T>;
   __shared__ __attribute__((aligned(16))) T featI[C::FEAT_ELEMS];
@@ -134,7 +137,9 @@ __global__ __launch_bounds__(GT) void gemm_rows_kernel(const T* __restrict__ fea
   const int id = blockIdx.x;
   const int j = id >> 3;
   const int per_row = n_slabs * n_mgroups;
-  const int bh = (j / per_row) * 8 + (id & 7);
+  // (rows_per_xcd > 0: an XCD takes a run of consecutive image rows -- feature rows do not end on 128-byte lines,
+  // and the line two rows share, read here and written in the output, then stays in one L2)
+  const int bh = rows_per_xcd ? (id & 7) * rows_per_xcd + j / per_row : (j / per_row) * 8 + (id & 7);
   if (bh >= n_rows) return;
   const int sub = j % per_row;
   const int n0 = (sub % n_slabs) * TS;
@@ -376,10 +381,12 @@ int run_gemms(const void* dCv, const rc_layout* lay, const void* f1, const void*
   RC_REQUIRE((int64_t)D * H * (W1 > W2 ? W1 : W2) * (int64_t)sizeof(T) < (1ll << 31) &&
                  (int64_t)W1 * W2p * (int64_t)sizeof(T) < (1ll << 31),
              RC_EUNSUPPORTED, "one image's feature maps (or one row's dense gradient) exceed 2 GiB");
+  const char* order = getenv("RC_BUILD_ROW_ORDER");  // as in rc_build_pyramid
+  const int rows_per_xcd = order && !strcmp(order, "interleaved") ? 0 : (int)(rows8 / 8);
   // d fmap1 = f2 . dC^T : n = w1, k = w2
 #define RC_GEMM_ROWS(TRANS, VEC, feat, out, N, K, ns)                                                             \
   hipLaunchKernelGGL((gemm_rows_kernel<T, TRANS, VEC>), dim3((unsigned)(rows8 * (ns) * my), 1, 1), dim3(GT), 0, st, \
-                     (const T*)(feat), dC, (T*)(out), D, N, K, H, W1, W2p, ns, my, (int)BH)
+                     (const T*)(feat), dC, (T*)(out), D, N, K, H, W1, W2p, ns, my, (int)BH, rows_per_xcd)
   if (v2) RC_GEMM_ROWS(false, true, f2, df1, W1, W2, ns1);
   else RC_GEMM_ROWS(false, false, f2, df1, W1, W2, ns1);
   int rc = rc_check_launch("rc_build_bwd(df1)");
