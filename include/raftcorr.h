@@ -134,8 +134,9 @@ int rc_grad_pyramid_layout(int64_t B, int64_t H, int64_t W1, int64_t W2, int L, 
  * already-rounded lower level (what avg_pool2d on a 16-bit volume does, corr.py:42).
  * Supported: (in,vol) = (F32,F32), (F16,F16), (BF16,BF16), (F16|BF16, F32).
  * Environment (read per call; cache policy and kernel choice only, the results are the same bits):
- * RC_BUILD_F1_POLICY=stream|plain -- f1 tiles fetched past the Infinity Cache or not (default: by the
- * pyramid's size, stream up to 200 MB); RC_BUILD_NO_DMA=1 -- the kernel without LDS-DMA;
+ * RC_BUILD_F1_POLICY=stream|plain -- stream: the pyramid is meant to stay in the Infinity Cache for the lookups
+ * (f1 tiles fetched past the cache, pyramid written with plain stores); plain: the pyramid is streamed out
+ * (default: by the pyramid's size, stream up to 200 MB); RC_BUILD_NO_DMA=1 -- the kernel without LDS-DMA;
  * RC_BUILD_ROW_ORDER=contiguous|interleaved -- image rows of one XCD (default: contiguous for 16-bit features).
  * RC_BUILD_F1_TILES=line|row -- f1 tiles start on 128-byte lines of memory or at the row's first column
  *   (default: line where the k planes are whole lines apart and the rows are not).

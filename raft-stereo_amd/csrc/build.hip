@@ -561,7 +561,8 @@ struct out_slab {
   uint32_t bytes, nb, kb;
 };
 // 16-byte block of group G of pixel `col` at the slab's level (shift `i`); cells outside the image are dropped
-template <int I>
+// KEEP: plain stores, the pyramid stays in the caches for the lookups (see build16g_kernel); else non-temporal
+template <int I, bool KEEP>
 __device__ __forceinline__ void slab_store16(const out_slab& sl, uint32_t blk_bytes, int W1, int col, int G, uint32_t a,
                                              uint32_t b, uint32_t c, uint32_t d) {
   uint32_t t = (uint32_t)(G - ((col >> I) >> 3)) + sl.kb;  // >= 0 by choice of bias
@@ -575,12 +576,13 @@ __device__ __forceinline__ void slab_store16(const out_slab& sl, uint32_t blk_by
     asm volatile("" ::"v"(v), "v"(off));
     return;
   }
-  __builtin_amdgcn_raw_buffer_store_b128(v, sl.rs, (int)off, 0, 2 /* nt */);
+  if constexpr (KEEP) __builtin_amdgcn_raw_buffer_store_b128(v, sl.rs, (int)off, 0, 0);
+  else __builtin_amdgcn_raw_buffer_store_b128(v, sl.rs, (int)off, 0, 2 /* nt */);
 }
 
 // epilogue of a 32 (w2) x 32 (w1) wave tile: acc[rt][ct], lane (g, li) holds rows n0 + 16 rt + 4 g + {0..3} of
 // column cw + 16 ct + li.  Exactly 2 (L < 3) or 3 store instructions.
-template <typename VT>
+template <typename VT, bool KEEP>
 __device__ __forceinline__ void epilogue16_g(const f4v (&acc)[2][2], float scale, const out_slab& s0, const out_slab& s2,
                                              uint32_t blk_bytes, int W1, int L, int n0, int cw) {
   const int lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
@@ -597,7 +599,7 @@ __device__ __forceinline__ void epilogue16_g(const f4v (&acc)[2][2], float scale
     }
     swap16(x[0][0], x[1][0]);
     swap16(x[0][1], x[1][1]);
-    slab_store16<0>(s0, blk_bytes, W1, col_sw, ((n0 + 16 * rt) >> 3) + (g >> 1), x[0][0], x[0][1], x[1][0], x[1][1]);
+    slab_store16<0, KEEP>(s0, blk_bytes, W1, col_sw, ((n0 + 16 * rt) >> 3) + (g >> 1), x[0][0], x[0][1], x[1][0], x[1][1]);
   }
   if (L < 3) return;  // level 1 is not stored; level 2 is its pairwise mean
   uint32_t w[4];      // w[ct] = level-2 values of row tiles 0, 1: block elements g and 4 + g
@@ -607,10 +609,16 @@ __device__ __forceinline__ void epilogue16_g(const f4v (&acc)[2][2], float scale
   transpose_rows(w);  // lane row j < 2: w[p] = elements (p, 4 + p) of the block of column tile j
   const uint32_t d0 = __builtin_amdgcn_perm(w[1], w[0], 0x05040100u), d1 = __builtin_amdgcn_perm(w[3], w[2], 0x05040100u);
   const uint32_t d2 = __builtin_amdgcn_perm(w[1], w[0], 0x07060302u), d3 = __builtin_amdgcn_perm(w[3], w[2], 0x07060302u);
-  slab_store16<2>(s2, blk_bytes, g < 2 ? W1 : 0, col_sw, n0 >> 5, d0, d1, d2, d3);
+  slab_store16<2, KEEP>(s2, blk_bytes, g < 2 ? W1 : 0, col_sw, n0 >> 5, d0, d1, d2, d3);
 }
 
-// F1_ONCE: the f1 tile is fetched non-temporally (glds16; the launcher decides by the pyramid's size)
+// F1_ONCE: the pyramid can stay in the 256 MiB Infinity Cache for the lookups (the launcher decides by its size).
+// The f1 tile, which has one reader, is then fetched non-temporally (glds16), and the pyramid is written with plain
+// stores instead of non-temporal ones: the build itself is 10 us slower for it (KITTI, 8 pairs: 102 -> 112 us; the
+// dirty pyramid lines compete with f2 in the L2), but every lookup finds the pyramid in the cache from the first
+// one on, 8.8 instead of 9.3 us on average over a step's 32 (after non-temporal stores the first lookup takes 14 us,
+// the second 11, and it is the eighth before they are down at 9): 0.416 -> 0.410 ms per step.  Level 2 alone
+// written plain: 0.413.  A larger pyramid is streamed out as before.
 template <typename T, bool F1_ONCE>
 __global__ __launch_bounds__(BT16, 4) void build16g_kernel(const T* __restrict__ f1, const T* __restrict__ f2,
                                                            T* __restrict__ vol, rc_dev_layout lay, float scale,
@@ -765,18 +773,18 @@ __global__ __launch_bounds__(BT16, 4) void build16g_kernel(const T* __restrict__
     if (c >= 1 && c + 1 < n_chunks) dma_tile<T>(f2row, ks2, W2, (c + 1) * C::TN, lds0 + ((c + 1) & 1) * G_BUF, wave);
     if (active) {
       if (late) {
-        if (c >= 1) epilogue16_g<T>(acc, scale, s0, s2, blk_bytes, W1, L, (c - 1) * C::TN + 32 * rh, cw);
+        if (c >= 1) epilogue16_g<T, F1_ONCE>(acc, scale, s0, s2, blk_bytes, W1, L, (c - 1) * C::TN + 32 * rh, cw);
         RC_STAMP(7 + 4 * c);
         multiply(c);
       } else {
         multiply(c);
         RC_STAMP(7 + 4 * c);
-        epilogue16_g<T>(acc, scale, s0, s2, blk_bytes, W1, L, c * C::TN + 32 * rh, cw);
+        epilogue16_g<T, F1_ONCE>(acc, scale, s0, s2, blk_bytes, W1, L, c * C::TN + 32 * rh, cw);
       }
       RC_STAMP(9 + 4 * c);
     }
   }
-  if (active && late) epilogue16_g<T>(acc, scale, s0, s2, blk_bytes, W1, L, (n_chunks - 1) * C::TN + 32 * rh, cw);
+  if (active && late) epilogue16_g<T, F1_ONCE>(acc, scale, s0, s2, blk_bytes, W1, L, (n_chunks - 1) * C::TN + 32 * rh, cw);
 }
 
 template <typename T, typename VT, int FAST>
