@@ -911,12 +911,18 @@ def main():
 
     for _ in range(args.warmup):
         step.run(record=False)
+    # the timed steps are eager and their launches run barely ahead of the GPU (8 us of host time beside a 9 us
+    # kernel): Python's cyclic collector is kept out of the timed region, as timeit keeps it out of its own
+    import gc
+    gc.collect()
+    gc.disable()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step.run(record=True)       # HIP events bracket the build and the lookups of every timed step
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     step.collect()                  # event times are read after the timed region
 
     if dist is not None:
