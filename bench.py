@@ -831,8 +831,10 @@ def cpu_baseline(cfg, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    # defaults: 100 timed steps after 10 (a step is 0.4 ms, 3.6 ms at the largest workload; 20 steps were 8 ms and
+    # noisy); under --profile 20 after 5, the command the committed profiles were collected with
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", default="kitti", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch")
     ap.add_argument("--dtype", choices=["f32", "f16", "bf16"], default=None, help="override the feature dtype")
@@ -850,6 +852,10 @@ def main():
     ap.add_argument("--debug-leg", choices=["loop_eager", "graph_step", "loop_capture"], default=None,
                     help="after the timed region run exactly one side leg (to bisect a fault under a profiler)")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 20 if args.profile else 100
+    if args.warmup is None:
+        args.warmup = 5 if args.profile else 10
     if args.profile:
         args.no_cpu_baseline = args.no_refine_loop = True
     if args.miopen_find and WORKLOADS[args.workload]["train"]:
