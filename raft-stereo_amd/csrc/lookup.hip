@@ -93,7 +93,9 @@ __global__ __launch_bounds__(LK_THREADS) void lookup_fwd_kernel(const VT* __rest
   const int L = ALL4 ? 4 : lay.L;
   const uint32_t blk_bytes = (uint32_t)lay.pitch * 16u;  // distance between block rows of a pixel
 
-  float x = (coords + uniform(((int64_t)b * coords_channels) * HW + it.p0))[lane];
+  // (non-temporal: the lookup is the coordinates' one reader here, and 32 iterations' worth of them, 61 MB at
+  // KITTI with 8 pairs, would otherwise sit in the Infinity Cache beside the pyramid: 8.63 -> 8.56 us per lookup)
+  float x = __builtin_nontemporal_load(coords + uniform(((int64_t)b * coords_channels) * HW + it.p0) + lane);
   if (upd.delta) {  // wave-uniform: the GRU iteration's coordinate update folded into this lookup
     // core/raft_stereo.py:120-123 (delta_flow[:,1] = 0; coords1 = coords1 + delta_flow) and :111
     // (flow = coords1 - coords0, coords0 = the pixel grid of core/utils/utils.py coords_grid)
