@@ -953,6 +953,13 @@ def main():
     else:
         roof = roof_entry("lookup_fwd_kernel", cnt["lookup_bytes"], lookup_ms * 1e3,
                           measured_traffic(args.workload, cfg["batch"], "lookup_fwd_kernel") if stock else (None, None))
+    if not is_alt:
+        # where the lookup's reads come from: a pyramid of up to 200 MB is left in the 256 MiB Infinity Cache by the
+        # build (rc_build_pyramid's size rule), so only the writes of such a lookup reach HBM and its rate can pass
+        # that of a copy; the HBM-resident figure is `roofline_hbm_resident` (64 pairs)
+        es = 4 if cfg["dtype"] == "f32" else 2
+        pyramid_bytes = cfg["batch"] * cfg["H"] * cfg["W"] * cfg["W"] * 1.25 * es
+        roof["pyramid_reads_from"] = "infinity_cache" if pyramid_bytes <= (200 << 20) else "hbm"
     ach = roof["achieved"]
     extra = dict(lookup_gbps=round(ach, 1), lookup_us=round(lookup_ms * 1e3, 2))
     if not is_alt:
