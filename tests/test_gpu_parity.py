@@ -262,6 +262,16 @@ def test_build_cache_policies_are_the_same_pyramid(R, dtype, shape, monkeypatch)
     gen = torch.Generator(device="cuda").manual_seed(23)
     f1 = torch.randn((B, D, H, W1), generator=gen, device="cuda").to(dtype)
     f2 = torch.randn((B, D, H, W2), generator=gen, device="cuda").to(dtype)
+
+    def at_offset(t, elems):  # the same values in storage that starts `elems` elements (16-byte pieces) into a line
+        flat = torch.empty(t.numel() + elems, dtype=t.dtype, device=t.device)
+        view = flat[elems:].view(t.shape)
+        view.copy_(t)
+        assert view.is_contiguous() and view.data_ptr() % 128 == (flat.data_ptr() + 2 * elems) % 128
+        return view
+
+    # (feature maps that do not start on a 128-byte line: the line-tile shift then comes from the pointer, too)
+    f1, f2 = at_offset(f1, 8 * (H % 5)), at_offset(f2, 8 * (W1 % 7))
     vols = {}
     for name, env in (("stream", {"RC_BUILD_F1_POLICY": "stream"}), ("plain", {"RC_BUILD_F1_POLICY": "plain"}),
                       ("no_dma", {"RC_BUILD_NO_DMA": "1"}), ("interleaved", {"RC_BUILD_ROW_ORDER": "interleaved"}),
