@@ -84,7 +84,7 @@ __global__ __launch_bounds__(LK_THREADS) void lookup_fwd_kernel(const VT* __rest
   // over several rounds of workgroups the plain order is the faster one (64 pairs: 86.9 against 88.6 us).
   int wg = blockIdx.x;
   if (upd.wgs_per_xcd > 0) wg = (int)(blockIdx.x & 7) * upd.wgs_per_xcd + (int)(blockIdx.x >> 3);
-  const int item = wg * (LK_THREADS / 64) + wave;  // (image, 64-pixel chunk), wave-uniform
+  const int item = wg * (int)(blockDim.x >> 6) + wave;  // (image, 64-pixel chunk), wave-uniform; 1 or 4 waves per workgroup
   if (item >= n_items) return;
   const px_item it = locate_item(item, chunks_per_image, lay.H, lay.W1, lane);
   if (!it.live) return;
@@ -649,15 +649,19 @@ int launch_fwd_mode(const void* vol, rc_dev_layout d, const float* coords, int c
   const int chunks = (d.H * d.W1 + 63) / 64;
   const int n_items = (int)((int64_t)d.B * chunks);
   int blocks = (n_items + (LK_THREADS / 64) - 1) / (LK_THREADS / 64);
+  int threads = LK_THREADS;
   lk_update updx = upd;
   updx.wgs_per_xcd = 0;
   if (blocks <= LK_ONE_ROUND_WGS) {  // see the kernel: an eighth of the pixels per XCD
-    updx.wgs_per_xcd = (blocks + 7) / 8;
+    // ... in workgroups of ONE wave: 3 744 of them spread over 256 CUs more evenly than 936 of four (KITTI, 8 pairs:
+    // 8.56 -> 8.48 us); a launch of several rounds is faster in fours (64 pairs: 86.5 against 90.1 us)
+    threads = 64;
+    updx.wgs_per_xcd = (n_items + 7) / 8;
     blocks = updx.wgs_per_xcd * 8;
   }
   const bool nts = (int64_t)d.B * d.L * (2 * R + 1) * d.H * d.W1 * (int64_t)sizeof(OT) > LK_NT_STORE_BYTES;
 #define RC_LK(ALL4, NTS)                                                                                       \
-  hipLaunchKernelGGL((lookup_fwd_kernel<VT, R, MODE, ALL4, NTS, OT>), dim3(blocks), dim3(LK_THREADS), 0, st,  \
+  hipLaunchKernelGGL((lookup_fwd_kernel<VT, R, MODE, ALL4, NTS, OT>), dim3(blocks), dim3(threads), 0, st,     \
                      (const VT*)vol, d, coords, cc, out, chunks, n_items, updx)
   if (R == 4 && d.L == 4) {  // the model's configuration: all levels' loads in flight together
     if (nts) RC_LK((R == 4), true);
